@@ -1,0 +1,302 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by ssvio_amd/.  PARITY UNPINNED: see
+oracle/ssvio_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+DM_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+assert KP_DTYPE.itemsize == 28 and DM_DTYPE.itemsize == 16
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "ssvio_oracle.h", "orb_pattern.inc")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+class _Grid(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("nCols", "nRows", "wCell", "hCell", "minBX", "minBY", "maxBX", "maxBY")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+        L.orc_cvround.restype = i32; L.orc_cvround.argtypes = [C.c_double]
+        L.orc_rgb2gray.argtypes = [vp, i32, i32, i32, vp, i32]
+        L.orc_resize_linear.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32]
+        L.orc_border_reflect101.argtypes = [vp, i32, i32, i32, i32]
+        L.orc_fast9.restype = i32; L.orc_fast9.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, i32]
+        L.orc_fast_score_ref.restype = i32; L.orc_fast_score_ref.argtypes = [vp, i32, i32]
+        L.orc_gaussian7.argtypes = [vp, i32, i32, i32, vp, i32]
+        L.orc_fast_atan2.restype = f32; L.orc_fast_atan2.argtypes = [f32, f32]
+        L.orc_sincosf.argtypes = [f32, vp, vp]
+        L.orc_gauss_kernel_fixed.argtypes = [vp]
+        L.orc_create.restype = vp; L.orc_create.argtypes = [i32, f32, i32, i32, i32]
+        L.orc_destroy.argtypes = [vp]
+        for n in ("orc_scale_factors", "orc_inv_scale_factors", "orc_level_sigma2", "orc_inv_level_sigma2",
+                  "orc_features_per_level", "orc_umax"):
+            getattr(L, n).restype = vp; getattr(L, n).argtypes = [vp]
+        L.orc_extract.restype = i32; L.orc_extract.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32]
+        L.orc_extract_rgb.restype = i32; L.orc_extract_rgb.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32]
+        L.orc_level_size.restype = i32; L.orc_level_size.argtypes = [vp, i32, vp, vp]
+        L.orc_level_roi.restype = vp; L.orc_level_roi.argtypes = [vp, i32, vp]
+        L.orc_level_blur.restype = vp; L.orc_level_blur.argtypes = [vp, i32, vp]
+        L.orc_level_candidates.restype = i32; L.orc_level_candidates.argtypes = [vp, i32, vp, vp, vp]
+        L.orc_level_keypoints.restype = i32; L.orc_level_keypoints.argtypes = [vp, i32, vp]
+        L.orc_level_tie_at_cut.restype = i32; L.orc_level_tie_at_cut.argtypes = [vp, i32]
+        L.orc_cell_grid.restype = i32; L.orc_cell_grid.argtypes = [i32, i32, vp]
+        L.orc_distribute_octtree.restype = i32
+        L.orc_distribute_octtree.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]
+        L.orc_ic_angle.restype = f32; L.orc_ic_angle.argtypes = [vp, i32, i32, i32, vp, vp]
+        L.orc_orb_descriptor.argtypes = [vp, i32, i32, i32, f32, vp]
+        L.orc_hamming256.restype = i32; L.orc_hamming256.argtypes = [vp, vp]
+        L.orc_knn2_raw.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp, vp]
+        L.orc_bf_nn.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp]
+        L.orc_match_bruteforce.restype = i32; L.orc_match_bruteforce.argtypes = [vp, i32, i32, vp, i32, i32, vp]
+        L.orc_match_knn2_ratio.restype = i32; L.orc_match_knn2_ratio.argtypes = [vp, i32, i32, vp, i32, i32, i32, f32, vp]
+        L.orc_match_crosscheck.restype = i32; L.orc_match_crosscheck.argtypes = [vp, i32, i32, vp, i32, i32, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+# ---------------------------------------------------------------- primitives
+def cvround(v): return lib().orc_cvround(float(v))
+
+
+def rgb2gray(rgb):
+    rgb = _u8(rgb); h, w, _ = rgb.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_rgb2gray(_p(rgb), w, h, rgb.strides[0], _p(out), w)
+    return out
+
+
+def resize_linear(src, dw, dh):
+    src = _u8(src); sh, sw = src.shape
+    out = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_linear(_p(src), sw, sh, src.strides[0], _p(out), dw, dh, dw)
+    return out
+
+
+def border_reflect101(img, pad):
+    img = _u8(img); h, w = img.shape
+    buf = np.zeros((h + 2 * pad, w + 2 * pad), np.uint8)
+    buf[pad:pad + h, pad:pad + w] = img
+    lib().orc_border_reflect101(_p(buf), w, h, buf.strides[0], pad)
+    return buf
+
+
+def fast9(img, threshold):
+    img = _u8(img); h, w = img.shape
+    cap = max(16, w * h)
+    xs = np.empty(cap, np.int32); ys = np.empty(cap, np.int32); sc = np.empty(cap, np.int32)
+    n = lib().orc_fast9(_p(img), w, h, img.strides[0], threshold, _p(xs), _p(ys), _p(sc), cap)
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def fast_score_ref(img, x, y, threshold):
+    img = _u8(img)
+    return lib().orc_fast_score_ref(C.c_void_p(img.ctypes.data + y * img.strides[0] + x), img.strides[0], threshold)
+
+
+def gaussian7(img):
+    img = _u8(img); h, w = img.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_gaussian7(_p(img), w, h, img.strides[0], _p(out), w)
+    return out
+
+
+def gauss_kernel_fixed():
+    k = np.zeros(7, np.int32); lib().orc_gauss_kernel_fixed(_p(k)); return k
+
+
+def fast_atan2(y, x): return lib().orc_fast_atan2(float(y), float(x))
+
+
+def sincosf(x):
+    s = C.c_float(); c = C.c_float()
+    lib().orc_sincosf(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def cell_grid(w, h):
+    g = _Grid()
+    rc = lib().orc_cell_grid(w, h, C.byref(g))
+    return None if rc else {n: getattr(g, n) for n, _ in _Grid._fields_}
+
+
+def distribute_octtree(xs, ys, resp, minX, maxX, minY, maxY, N):
+    xs = np.ascontiguousarray(xs, np.float32); ys = np.ascontiguousarray(ys, np.float32)
+    resp = np.ascontiguousarray(resp, np.float32)
+    n = len(xs); cap = n + 8
+    out = np.empty(cap, np.int32); tie = C.c_int(0)
+    m = lib().orc_distribute_octtree(_p(xs), _p(ys), _p(resp), n, minX, maxX, minY, maxY, N, _p(out), cap, C.byref(tie))
+    if m < 0:
+        raise ValueError("degenerate quadtree geometry")
+    return out[:m].copy(), bool(tie.value)
+
+
+def ic_angle(img, x, y):
+    img = _u8(img)
+    m01 = C.c_int(); m10 = C.c_int()
+    a = lib().orc_ic_angle(_p(img), img.strides[0], x, y, C.byref(m01), C.byref(m10))
+    return a, m01.value, m10.value
+
+
+def orb_descriptor(blurred, x, y, angle_deg):
+    blurred = _u8(blurred)
+    d = np.empty(32, np.uint8)
+    lib().orc_orb_descriptor(_p(blurred), blurred.strides[0], x, y, float(angle_deg), _p(d))
+    return d
+
+
+# ---------------------------------------------------------------- extractor
+class Extractor:
+    """Mirror of ORBextractor (include/Feature.h:32-103) on the oracle."""
+
+    def __init__(self, nfeatures=1200, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self._h = lib().orc_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self._h:
+            raise ValueError("bad extractor parameters")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_destroy(self._h); self._h = None
+
+    def _arr(self, fn, ctype, n):
+        p = getattr(lib(), fn)(self._h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(n,)).copy()
+
+    def scale_factors(self): return self._arr("orc_scale_factors", C.c_float, self.nlevels)
+    def inv_scale_factors(self): return self._arr("orc_inv_scale_factors", C.c_float, self.nlevels)
+    def level_sigma2(self): return self._arr("orc_level_sigma2", C.c_float, self.nlevels)
+    def inv_level_sigma2(self): return self._arr("orc_inv_level_sigma2", C.c_float, self.nlevels)
+    def features_per_level(self): return self._arr("orc_features_per_level", C.c_int, self.nlevels)
+    def umax(self): return self._arr("orc_umax", C.c_int, 16)
+
+    def extract(self, gray):
+        gray = _u8(gray); h, w = gray.shape
+        cap = self.nfeatures + 8 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        n = lib().orc_extract(self._h, _p(gray), w, h, gray.strides[0], _p(kps), _p(desc), cap)
+        if n < 0:
+            raise ValueError("image too small / degenerate for this pyramid")
+        return kps[:n].copy(), desc[:n].copy()
+
+    def extract_rgb(self, rgb):
+        rgb = _u8(rgb); h, w, _ = rgb.shape
+        cap = self.nfeatures + 8 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        n = lib().orc_extract_rgb(self._h, _p(rgb), w, h, rgb.strides[0], _p(kps), _p(desc), cap)
+        if n < 0:
+            raise ValueError("image too small / degenerate for this pyramid")
+        return kps[:n].copy(), desc[:n].copy()
+
+    # intermediates of the last extract()
+    def level_size(self, l):
+        w = C.c_int(); h = C.c_int()
+        if lib().orc_level_size(self._h, l, C.byref(w), C.byref(h)):
+            raise IndexError(l)
+        return w.value, h.value
+
+    def _img(self, fn, l):
+        w, h = self.level_size(l)
+        st = C.c_int()
+        p = getattr(lib(), fn)(self._h, l, C.byref(st))
+        if not p:
+            return None
+        buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=((h - 1) * st.value + w,))
+        return np.lib.stride_tricks.as_strided(buf, (h, w), (st.value, 1)).copy()
+
+    def level_image(self, l): return self._img("orc_level_roi", l)
+    def level_blur(self, l): return self._img("orc_level_blur", l)
+
+    def level_candidates(self, l):
+        xs = C.c_void_p(); ys = C.c_void_p(); rs = C.c_void_p()
+        n = lib().orc_level_candidates(self._h, l, C.byref(xs), C.byref(ys), C.byref(rs))
+        f = lambda p: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).copy() if n else np.zeros(0, np.float32)
+        return f(xs), f(ys), f(rs)
+
+    def level_keypoints(self, l):
+        p = C.c_void_p()
+        n = lib().orc_level_keypoints(self._h, l, C.byref(p))
+        if n == 0:
+            return np.zeros(0, KP_DTYPE)
+        raw = C.string_at(p, n * 28)
+        return np.frombuffer(raw, KP_DTYPE).copy()
+
+    def level_tie_at_cut(self, l): return bool(lib().orc_level_tie_at_cut(self._h, l))
+
+
+# ---------------------------------------------------------------- matching
+def _desc(a):
+    a = _u8(a)
+    assert a.ndim == 2 and a.shape[1] == 32
+    return a
+
+
+def hamming256(a, b):
+    a = _u8(a); b = _u8(b)
+    return lib().orc_hamming256(_p(a), _p(b))
+
+
+def knn2_raw(q, t):
+    q = _desc(q); t = _desc(t)
+    idx = np.empty(len(q), np.int32); d1 = np.empty(len(q), np.int32); d2 = np.empty(len(q), np.int32)
+    lib().orc_knn2_raw(_p(q), len(q), 32, _p(t), len(t), 32, _p(idx), _p(d1), _p(d2))
+    return idx, d1, d2
+
+
+def bf_nn(q, t):
+    q = _desc(q); t = _desc(t)
+    idx = np.empty(len(q), np.int32); d = np.empty(len(q), np.int32)
+    lib().orc_bf_nn(_p(q), len(q), 32, _p(t), len(t), 32, _p(idx), _p(d))
+    return idx, d
+
+
+def match_bruteforce(q, t):
+    q = _desc(q); t = _desc(t)
+    out = np.zeros(max(len(q), 1), DM_DTYPE)
+    n = lib().orc_match_bruteforce(_p(q), len(q), 32, _p(t), len(t), 32, _p(out))
+    return out[:n].copy()
+
+
+def match_knn2_ratio(q, t, threshold=50, nn_ratio=0.6):
+    q = _desc(q); t = _desc(t)
+    out = np.zeros(max(len(q), 1), DM_DTYPE)
+    n = lib().orc_match_knn2_ratio(_p(q), len(q), 32, _p(t), len(t), 32, threshold, nn_ratio, _p(out))
+    return out[:n].copy()
+
+
+def match_crosscheck(q, t):
+    q = _desc(q); t = _desc(t)
+    out = np.zeros(max(len(q), 1), DM_DTYPE)
+    n = lib().orc_match_crosscheck(_p(q), len(q), 32, _p(t), len(t), 32, _p(out))
+    return out[:n].copy()
