@@ -1,0 +1,8 @@
+"""ssvio_amd -- MI355X (gfx950) ORB extraction + brute-force Hamming matching behind
+SSVIO's ORBextractor / FeatureMatching interfaces.  See DESIGN.md."""
+from ._lib import KP_DTYPE, DM_DTYPE, SsvioError, device_count, MODE_BRUTEFORCE, MODE_KNN2_RATIO, MODE_CROSSCHECK
+from .extractor import ORBextractor, distribute_octtree
+from .matching import FeatureMatching
+
+__all__ = ["ORBextractor", "FeatureMatching", "distribute_octtree", "KP_DTYPE", "DM_DTYPE", "SsvioError",
+           "device_count", "MODE_BRUTEFORCE", "MODE_KNN2_RATIO", "MODE_CROSSCHECK"]

@@ -1,0 +1,116 @@
+"""ctypes loader for libssvio_gpu.so (C ABI: include/ssvio_gpu.h).
+
+There is no CPU fallback: if the HIP library is missing the import fails loudly,
+and without a GPU every create() raises SsvioError(SSVIO_ERR_NOGPU).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssvio_gpu.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_GEOMETRY, ERR_NOGPU = 0, -1, -2, -3, -4, -5
+MAX_LEVELS = 16
+MODE_BRUTEFORCE, MODE_KNN2_RATIO, MODE_CROSSCHECK = 0, 1, 2
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])   # cv::KeyPoint
+DM_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])  # cv::DMatch
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class SsvioError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ssvio error %d: %s" % (code, msg))
+        self.code = code
+
+
+# every symbol include/ssvio_gpu.h declares: name -> (restype, argtypes)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SYMBOLS = {
+    "ssvio_last_error": (C.c_char_p, []),
+    "ssvio_version": (_i, []),
+    "ssvio_device_count": (_i, [_vp]),
+    "ssvio_orb_create": (_i, [_vp, _i, _vp]),
+    "ssvio_orb_destroy": (None, [_vp]),
+    "ssvio_orb_get_tables": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssvio_orb_max_keypoints": (_i, [_vp]),
+    "ssvio_orb_level_geometry": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssvio_orb_extract": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "ssvio_orb_extract_rgb": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "ssvio_orb_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _sz, _vp, _vp, _i, _vp]),
+    "ssvio_orb_extract_batch_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _sz]),
+    "ssvio_orb_device_results": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "ssvio_orb_fetch_results": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "ssvio_orb_last_counts": (_i, [_vp, _i, _vp]),
+    "ssvio_orb_pyramid_level": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    "ssvio_orb_debug_level_image": (_i, [_vp, _i, _i, _i, _vp, _i]),
+    "ssvio_orb_debug_candidates": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "ssvio_distribute_octtree": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "ssvio_orb_set_profiling": (_i, [_vp, _i]),
+    "ssvio_orb_kernel_times": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "ssvio_orb_set_stream": (_i, [_vp, _vp]),
+    "ssvio_matcher_create": (_i, [_i, _f, _i, _vp]),
+    "ssvio_matcher_destroy": (None, [_vp]),
+    "ssvio_matcher_set_stream": (_i, [_vp, _vp]),
+    "ssvio_matcher_set_profiling": (_i, [_vp, _i]),
+    "ssvio_matcher_kernel_times": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "ssvio_match_bruteforce": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "ssvio_match_knn2_ratio": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "ssvio_match_crosscheck": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "ssvio_match_knn2_raw": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "ssvio_match_batch_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "ssvio_matcher_sync": (_i, [_vp]),
+    "ssvio_match_batch_fetch": (_i, [_vp, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libssvio_gpu.so is not built (%s). Build it with "
+                              "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C ssvio_amd/csrc`. "
+                              "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise SsvioError(rc, (lib().ssvio_last_error() or b"").decode())
+
+
+def ptr(a):
+    """void* of a numpy array or of anything with data_ptr() (torch tensor) or a raw int."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().ssvio_device_count(C.byref(n)))
+    return n.value
+
+
+def kernel_times(fn, handle):
+    names = (C.c_char_p * 32)(); ms = (C.c_double * 32)(); launches = (C.c_int32 * 32)(); cnt = C.c_int(0)
+    check(fn(handle, names, ms, launches, 32, C.byref(cnt)))
+    return {names[i].decode(): (ms[i], launches[i]) for i in range(min(cnt.value, 32))}

@@ -1,0 +1,885 @@
+// capi.hip -- the C ABI of include/ssvio_gpu.h: handles, device memory, streams and
+// the per-batch orchestration of the gfx950 kernels.
+#include "common.h"
+#include "match.h"
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+namespace ssvio {
+const char* last_error_cstr();
+
+// ---------------------------------------------------------------- profiler
+hipEvent_t KernelProfiler::get()
+{
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+void KernelProfiler::begin(const char* name, hipStream_t s)
+{
+    Rec r{name, get(), get()};
+    (void)hipEventRecord(r.a, s);
+    pending.push_back(r);
+}
+void KernelProfiler::end(hipStream_t s) { (void)hipEventRecord(pending.back().b, s); }
+void KernelProfiler::resolve()
+{
+    for (auto& r : pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto it = std::find_if(stats.begin(), stats.end(), [&](const Stat& s) { return s.name == r.name; });
+            if (it == stats.end()) stats.push_back(Stat{r.name, ms, 1});
+            else { it->ms += ms; it->launches++; }
+        }
+        pool.push_back(r.a); pool.push_back(r.b);
+    }
+    pending.clear();
+}
+void KernelProfiler::clear() { resolve(); stats.clear(); }
+void KernelProfiler::destroy()
+{
+    for (auto& r : pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : pool) (void)hipEventDestroy(e);
+    pending.clear(); pool.clear(); stats.clear();
+}
+
+// ---------------------------------------------------------------- host worker pool (quadtree stage)
+class WorkerPool {
+public:
+    explicit WorkerPool(int n) {
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // runs fn(i) for i in [0,n) on the pool plus the calling thread; returns when all are done
+    // and no worker is still inside the claim loop (so the next run may reset the counters)
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (th_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+        {
+            std::unique_lock<std::mutex> l(m_);
+            dcv_.wait(l, [&] { return active_ == 0; });
+            fn_ = &fn; n_ = n; next_.store(0); done_.store(0); ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> l(m_);
+        dcv_.wait(l, [&] { return done_.load() >= n_ && active_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void work() {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*fn_)(i);
+            done_.fetch_add(1);
+        }
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                ++active_;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> l(m_);
+                --active_;
+            }
+            dcv_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_; std::condition_variable cv_, dcv_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int n_ = 0; std::atomic<int> next_{0}, done_{0};
+    int active_ = 0;
+    unsigned long gen_ = 0; bool stop_ = false;
+};
+
+static int host_threads()
+{
+    if (const char* e = std::getenv("SSVIO_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1) return std::min(v, 64); }
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(hc ? hc : 4, 16);
+}
+
+static int pick_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible: this library has no CPU fallback");
+        return SSVIO_ERR_NOGPU;
+    }
+    if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return SSVIO_ERR_INVALID; }
+    return SSVIO_OK;
+}
+
+template <typename T> static void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+template <typename T> static void hfree(T*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } }
+
+}  // namespace ssvio
+
+using namespace ssvio;
+
+// =====================================================================================
+struct ssvio_orb {
+    int device = 0;
+    ExtractorTables tab{};
+    PyramidGeom geom{};
+    KLevels kl{};
+    hipStream_t own = nullptr, stream = nullptr;
+    hipEvent_t evCand = nullptr;
+    int batchCap = 0;
+    int kpCap = 0;                 // keypoints per frame
+    int candCap = 0;               // candidates per frame (all levels)
+    size_t inBytes = 0;
+    uint8_t* d_in = nullptr; uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr;
+    int16_t* d_tabs = nullptr; std::vector<size_t> xTabOff, yTabOff;
+    uint32_t* d_slots = nullptr; int* d_cellCount = nullptr;
+    uint32_t* d_cand = nullptr; int* d_candCount = nullptr;
+    uint2* d_kpIn = nullptr; int* d_kpCount = nullptr;
+    ssvio_keypoint* d_kpOut = nullptr; uint8_t* d_desc = nullptr;
+    uint32_t* h_cand = nullptr; int* h_candCount = nullptr; uint2* h_kpIn = nullptr; int* h_kpCount = nullptr;
+    KernelProfiler prof;
+    std::unique_ptr<WorkerPool> pool;
+    int lastBatch = 0;
+    bool haveResults = false;
+};
+
+static void orb_free_buffers(ssvio_orb* h)
+{
+    dfree(h->d_in); dfree(h->d_pyr); dfree(h->d_blur); dfree(h->d_tabs); dfree(h->d_slots); dfree(h->d_cellCount);
+    dfree(h->d_cand); dfree(h->d_candCount); dfree(h->d_kpIn); dfree(h->d_kpCount); dfree(h->d_kpOut); dfree(h->d_desc);
+    hfree(h->h_cand); hfree(h->h_candCount); hfree(h->h_kpIn); hfree(h->h_kpCount);
+    h->batchCap = 0; h->inBytes = 0; h->haveResults = false;
+}
+
+static void fill_klevels(const PyramidGeom& g, KLevels& k)
+{
+    memset(&k, 0, sizeof k);
+    k.nlevels = g.nlevels;
+    for (int l = 0; l < g.nlevels; ++l) {
+        const LevelGeom& L = g.lv[l];
+        k.w[l] = L.w; k.h[l] = L.h; k.pitch[l] = L.pitch; k.offset[l] = L.offset;
+        k.nCols[l] = L.nCols; k.nRows[l] = L.nRows; k.wCell[l] = L.wCell; k.hCell[l] = L.hCell;
+        k.cellBase[l] = L.cellBase; k.slotCap[l] = L.slotCap; k.slotBase[l] = L.slotBase;
+        k.blurTileBase[l] = L.blurTileBase; k.blurTilesX[l] = L.blurTilesX;
+        k.scale[l] = L.scale; k.kpSize[l] = L.kpSize;
+    }
+    k.cellBase[g.nlevels] = g.cellsPerFrame;
+    k.blurTileBase[g.nlevels] = g.blurTilesPerFrame;
+}
+
+// (re)allocate for a w x h x batch configuration
+static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inBytes)
+{
+    SSVIO_HIP(hipSetDevice(h->device));
+    const bool geomChange = width != h->geom.width || height != h->geom.height;
+    if (geomChange) {
+        PyramidGeom g;
+        const int rc = build_geometry(h->tab, width, height, g);
+        if (rc) return rc;
+        SSVIO_HIP(hipStreamSynchronize(h->stream));
+        orb_free_buffers(h);
+        h->geom = g;
+        fill_klevels(g, h->kl);
+        // resize tables
+        std::vector<int16_t> all;
+        h->xTabOff.assign(g.nlevels, 0); h->yTabOff.assign(g.nlevels, 0);
+        for (int l = 1; l < g.nlevels; ++l) {
+            ResizeTabs t;
+            build_resize_tabs(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h, t);
+            h->xTabOff[l] = all.size(); all.insert(all.end(), t.xs.begin(), t.xs.end());
+            h->yTabOff[l] = all.size(); all.insert(all.end(), t.ys.begin(), t.ys.end());
+        }
+        if (all.empty()) all.resize(4);
+        SSVIO_HIP(hipMalloc(&h->d_tabs, all.size() * sizeof(int16_t)));
+        SSVIO_HIP(hipMemcpy(h->d_tabs, all.data(), all.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    }
+    if (batch > h->batchCap) {
+        SSVIO_HIP(hipStreamSynchronize(h->stream));
+        int16_t* tabs = h->d_tabs; h->d_tabs = nullptr;     // keep the tables
+        orb_free_buffers(h);
+        h->d_tabs = tabs;
+        const PyramidGeom& g = h->geom;
+        const size_t B = (size_t)batch;
+        h->kpCap = g.maxQuotaSum + 4 * g.nlevels;
+        if (h->candCap == 0) h->candCap = std::max(8192, 8 * h->tab.nfeatures);
+        SSVIO_HIP(hipMalloc(&h->d_pyr, B * g.frameBytes));
+        SSVIO_HIP(hipMalloc(&h->d_blur, B * g.frameBytes));
+        SSVIO_HIP(hipMemsetAsync(h->d_pyr, 0, B * g.frameBytes, h->stream));
+        SSVIO_HIP(hipMemsetAsync(h->d_blur, 0, B * g.frameBytes, h->stream));
+        SSVIO_HIP(hipMalloc(&h->d_slots, B * g.slotsPerFrame * sizeof(uint32_t)));
+        SSVIO_HIP(hipMalloc(&h->d_cellCount, B * g.cellsPerFrame * sizeof(int)));
+        SSVIO_HIP(hipMalloc(&h->d_cand, B * h->candCap * sizeof(uint32_t)));
+        SSVIO_HIP(hipMalloc(&h->d_candCount, B * (kMaxLevels + 1) * sizeof(int)));
+        SSVIO_HIP(hipMalloc(&h->d_kpIn, B * h->kpCap * sizeof(uint2)));
+        SSVIO_HIP(hipMalloc(&h->d_kpCount, B * sizeof(int)));
+        SSVIO_HIP(hipMalloc(&h->d_kpOut, B * h->kpCap * sizeof(ssvio_keypoint)));
+        SSVIO_HIP(hipMalloc(&h->d_desc, B * h->kpCap * 32));
+        SSVIO_HIP(hipHostMalloc(&h->h_cand, B * h->candCap * sizeof(uint32_t), hipHostMallocDefault));
+        SSVIO_HIP(hipHostMalloc(&h->h_candCount, B * (kMaxLevels + 1) * sizeof(int), hipHostMallocDefault));
+        SSVIO_HIP(hipHostMalloc(&h->h_kpIn, B * h->kpCap * sizeof(uint2), hipHostMallocDefault));
+        SSVIO_HIP(hipHostMalloc(&h->h_kpCount, B * sizeof(int), hipHostMallocDefault));
+        h->batchCap = batch;
+    }
+    if (inBytes > h->inBytes) {
+        SSVIO_HIP(hipStreamSynchronize(h->stream));
+        dfree(h->d_in);
+        SSVIO_HIP(hipMalloc(&h->d_in, inBytes));
+        h->inBytes = inBytes;
+    }
+    return SSVIO_OK;
+}
+
+// grow the per-frame candidate capacity (rare: very dense frames)
+static int orb_grow_cand(ssvio_orb* h, int need)
+{
+    SSVIO_HIP(hipStreamSynchronize(h->stream));
+    dfree(h->d_cand); hfree(h->h_cand);
+    h->candCap = need + need / 2;
+    SSVIO_HIP(hipMalloc(&h->d_cand, (size_t)h->batchCap * h->candCap * sizeof(uint32_t)));
+    SSVIO_HIP(hipHostMalloc(&h->h_cand, (size_t)h->batchCap * h->candCap * sizeof(uint32_t), hipHostMallocDefault));
+    return SSVIO_OK;
+}
+
+// the whole pipeline for `batch` frames whose level-0 images are already in d_pyr
+static int orb_run(ssvio_orb* h, int batch)
+{
+    const PyramidGeom& g = h->geom;
+    hipStream_t s = h->stream;
+    for (int l = 1; l < g.nlevels; ++l) {
+        ProfScope p(h->prof, "k_resize", s);
+        launch_resize(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], batch, s);
+    }
+    {
+        ProfScope p(h->prof, "k_fast_cells", s);
+        launch_fast(h->d_pyr, g.frameBytes, h->kl, g.cellsPerFrame, g.slotsPerFrame, h->tab.iniTh, h->tab.minTh,
+                    h->d_slots, h->d_cellCount, batch, s);
+    }
+    for (int attempt = 0;; ++attempt) {
+        {
+            ProfScope p(h->prof, "k_compact", s);
+            launch_compact(h->kl, g.cellsPerFrame, g.slotsPerFrame, h->d_slots, h->d_cellCount, h->d_cand, h->candCap, h->d_candCount, batch, s);
+        }
+        SSVIO_HIP(hipMemcpyAsync(h->h_candCount, h->d_candCount, (size_t)batch * (kMaxLevels + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(h->h_cand, h->d_cand, (size_t)batch * h->candCap * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipEventRecord(h->evCand, s));
+        if (attempt == 0) {
+            // the blur does not depend on the keypoints: it runs while the host distributes them
+            ProfScope p(h->prof, "k_blur", s);
+            launch_blur(h->d_pyr, h->d_blur, g.frameBytes, h->kl, g.blurTilesPerFrame, batch, s);
+        }
+        SSVIO_HIP(hipEventSynchronize(h->evCand));
+        int need = 0;
+        for (int f = 0; f < batch; ++f) need = std::max(need, h->h_candCount[f * (kMaxLevels + 1) + kMaxLevels]);
+        if (need <= h->candCap) break;
+        if (attempt >= 2) { set_error("internal: candidate buffer growth failed"); return SSVIO_ERR_HIP; }
+        const int rc = orb_grow_cand(h, need);
+        if (rc) return rc;
+    }
+    // host stage: DistributeOctTree per (frame, level), src/Feature.cpp:897-909
+    const int L = g.nlevels;
+    std::vector<std::vector<int>> sel((size_t)batch * L);
+    std::atomic<int> fail{0};
+    auto job = [&](int j) {
+        const int f = j / L, l = j % L;
+        const int* cnt = h->h_candCount + f * (kMaxLevels + 1);
+        int off = 0;
+        for (int i = 0; i < l; ++i) off += cnt[i];
+        const int n = cnt[l];
+        const uint32_t* c = h->h_cand + (size_t)f * h->candCap + off;
+        std::vector<float> xs(n), ys(n), rs(n);
+        for (int i = 0; i < n; ++i) { xs[i] = (float)(c[i] & 0xFFF); ys[i] = (float)((c[i] >> 12) & 0xFFF); rs[i] = (float)(c[i] >> 24); }
+        const LevelGeom& G = g.lv[l];
+        if (n == 0) { sel[j].clear(); return; }
+        if (distribute_octtree(xs.data(), ys.data(), rs.data(), n, kMinBorder, G.maxBX, kMinBorder, G.maxBY, G.quota, sel[j])) fail.store(1);
+    };
+    h->pool->run(batch * L, job);
+    if (fail.load()) return SSVIO_ERR_GEOMETRY;
+    for (int f = 0; f < batch; ++f) {
+        const int* cnt = h->h_candCount + f * (kMaxLevels + 1);
+        uint2* kp = h->h_kpIn + (size_t)f * h->kpCap;
+        int n = 0, off = 0;
+        for (int l = 0; l < L; ++l) {
+            const uint32_t* c = h->h_cand + (size_t)f * h->candCap + off;
+            for (int idx : sel[(size_t)f * L + l]) {
+                if (n >= h->kpCap) { set_error("internal: keypoint capacity %d exceeded", h->kpCap); return SSVIO_ERR_CAPACITY; }
+                const uint32_t e = c[idx];
+                const uint32_t x = (e & 0xFFF) + kMinBorder, y = ((e >> 12) & 0xFFF) + kMinBorder;   // src/Feature.cpp:905-906
+                kp[n++] = make_uint2(x | (y << 16), (uint32_t)l | ((e >> 24) << 8));
+            }
+            off += cnt[l];
+        }
+        h->h_kpCount[f] = n;
+    }
+    SSVIO_HIP(hipMemcpyAsync(h->d_kpIn, h->h_kpIn, (size_t)batch * h->kpCap * sizeof(uint2), hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(h->d_kpCount, h->h_kpCount, (size_t)batch * sizeof(int), hipMemcpyHostToDevice, s));
+    {
+        ProfScope p(h->prof, "k_describe", s);
+        launch_describe(h->d_pyr, h->d_blur, g.frameBytes, h->kl, h->d_kpIn, h->d_kpCount, h->kpCap, h->d_kpOut, h->d_desc, batch, s);
+    }
+    h->lastBatch = batch; h->haveResults = true;
+    return SSVIO_OK;
+}
+
+static int orb_check(ssvio_orb* h) { if (!h) { set_error("null extractor handle"); return SSVIO_ERR_INVALID; } return SSVIO_OK; }
+
+extern "C" {
+
+const char* ssvio_last_error(void) { return last_error_cstr(); }
+int ssvio_version(void) { return 100; }
+int ssvio_device_count(int* count)
+{
+    if (!count) { set_error("null count"); return SSVIO_ERR_INVALID; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return SSVIO_OK;
+}
+
+int ssvio_orb_create(const ssvio_orb_params* params, int device, ssvio_orb** out)
+{
+    if (!params || !out) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    *out = nullptr;
+    ExtractorTables t;
+    int rc = build_tables(*params, t);
+    if (rc) return rc;
+    rc = pick_device(device);
+    if (rc) return rc;
+    SSVIO_HIP(hipSetDevice(device));
+    ssvio_orb* h = new ssvio_orb();
+    h->device = device; h->tab = t;
+    if (hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->evCand, hipEventDisableTiming) != hipSuccess) {
+        set_error("cannot create HIP stream/event"); delete h; return SSVIO_ERR_HIP;
+    }
+    h->stream = h->own;
+    h->pool.reset(new WorkerPool(host_threads() - 1));
+    *out = h;
+    return SSVIO_OK;
+}
+
+void ssvio_orb_destroy(ssvio_orb* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    h->prof.resolve(); h->prof.destroy();
+    orb_free_buffers(h);
+    dfree(h->d_tabs);
+    if (h->evCand) (void)hipEventDestroy(h->evCand);
+    if (h->own) (void)hipStreamDestroy(h->own);
+    delete h;
+}
+
+int ssvio_orb_get_tables(ssvio_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* fpl)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    for (int i = 0; i < h->tab.nlevels; ++i) {
+        if (scale) scale[i] = h->tab.scale[i];
+        if (inv_scale) inv_scale[i] = h->tab.invScale[i];
+        if (sigma2) sigma2[i] = h->tab.sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->tab.invSigma2[i];
+        if (fpl) fpl[i] = h->tab.quota[i];
+    }
+    return SSVIO_OK;
+}
+
+int ssvio_orb_max_keypoints(ssvio_orb* h)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    int s = 0;
+    for (int i = 0; i < h->tab.nlevels; ++i) s += h->tab.quota[i];
+    return s + 4 * h->tab.nlevels;
+}
+
+int ssvio_orb_level_geometry(ssvio_orb* h, int width, int height, int level, int32_t* lw, int32_t* lh,
+                             int32_t* ncols, int32_t* nrows, int32_t* wcell, int32_t* hcell)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    if (level < 0 || level >= h->tab.nlevels) { set_error("level out of range"); return SSVIO_ERR_INVALID; }
+    PyramidGeom g;
+    const int rc = build_geometry(h->tab, width, height, g);
+    if (rc) return rc;
+    const LevelGeom& L = g.lv[level];
+    if (lw) *lw = L.w; if (lh) *lh = L.h; if (ncols) *ncols = L.nCols; if (nrows) *nrows = L.nRows;
+    if (wcell) *wcell = L.wCell; if (hcell) *hcell = L.hCell;
+    return SSVIO_OK;
+}
+
+int ssvio_orb_extract_batch_dev(ssvio_orb* h, const void* d_imgs, int batch, int channels,
+                                int width, int height, int stride, size_t frame_stride)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    if (channels != 1 && channels != 3) { set_error("channels must be 1 or 3"); return SSVIO_ERR_INVALID; }
+    if (batch < 0) { set_error("negative batch"); return SSVIO_ERR_INVALID; }
+    if (!d_imgs || width <= 0 || height <= 0 || batch == 0) { h->lastBatch = 0; h->haveResults = false; return SSVIO_OK; }   // src/Feature.cpp:507-508
+    if (stride < width * channels) { set_error("stride %d < row bytes %d", stride, width * channels); return SSVIO_ERR_INVALID; }
+    int rc = orb_ensure(h, width, height, batch, 0);
+    if (rc) return rc;
+    const PyramidGeom& g = h->geom;
+    {
+        ProfScope p(h->prof, channels == 3 ? "k_rgb2gray" : "k_copy_gray", h->stream);
+        if (channels == 3) launch_rgb2gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr, g.frameBytes, g.lv[0].pitch, h->stream);
+        else launch_copy_gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr, g.frameBytes, g.lv[0].pitch, h->stream);
+    }
+    rc = orb_run(h, batch);
+    if (rc) return rc;
+    SSVIO_HIP(hipStreamSynchronize(h->stream));
+    h->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_orb_fetch_results(ssvio_orb* h, int batch, ssvio_keypoint* kps, uint8_t* desc, int cap, int* n)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    if (!n) { set_error("null count array"); return SSVIO_ERR_INVALID; }
+    if (batch > h->lastBatch || !h->haveResults) {
+        if (h->lastBatch == 0) { for (int f = 0; f < batch; ++f) n[f] = 0; return SSVIO_OK; }
+        set_error("no results for %d frames (last call had %d)", batch, h->lastBatch); return SSVIO_ERR_INVALID;
+    }
+    SSVIO_HIP(hipSetDevice(h->device));
+    for (int f = 0; f < batch; ++f) {
+        const int c = h->h_kpCount[f];
+        if (c > cap) { set_error("frame %d has %d keypoints, caller capacity is %d", f, c, cap); return SSVIO_ERR_CAPACITY; }
+    }
+    for (int f = 0; f < batch; ++f) {
+        const int c = h->h_kpCount[f];
+        n[f] = c;
+        if (c == 0) continue;
+        if (kps) SSVIO_HIP(hipMemcpyAsync(kps + (size_t)f * cap, h->d_kpOut + (size_t)f * h->kpCap, (size_t)c * sizeof(ssvio_keypoint), hipMemcpyDeviceToHost, h->stream));
+        if (desc) SSVIO_HIP(hipMemcpyAsync(desc + (size_t)f * cap * 32, h->d_desc + (size_t)f * h->kpCap * 32, (size_t)c * 32, hipMemcpyDeviceToHost, h->stream));
+    }
+    SSVIO_HIP(hipStreamSynchronize(h->stream));
+    return SSVIO_OK;
+}
+
+int ssvio_orb_last_counts(ssvio_orb* h, int batch, int* n)
+{
+    if (orb_check(h) || !n) return SSVIO_ERR_INVALID;
+    for (int f = 0; f < batch; ++f) n[f] = (h->haveResults && f < h->lastBatch) ? h->h_kpCount[f] : 0;
+    return SSVIO_OK;
+}
+
+int ssvio_orb_device_results(ssvio_orb* h, const void** d_kps, const void** d_desc, const int32_t** d_n, int* cap_per_frame)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    if (!h->haveResults) { set_error("no device results yet"); return SSVIO_ERR_INVALID; }
+    if (d_kps) *d_kps = h->d_kpOut; if (d_desc) *d_desc = h->d_desc; if (d_n) *d_n = h->d_kpCount; if (cap_per_frame) *cap_per_frame = h->kpCap;
+    return SSVIO_OK;
+}
+
+int ssvio_orb_extract_batch(ssvio_orb* h, const uint8_t* imgs, int batch, int channels, int width, int height, int stride,
+                            size_t frame_stride, ssvio_keypoint* kps, uint8_t* desc, int cap, int* n)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    if (channels != 1 && channels != 3) { set_error("channels must be 1 or 3"); return SSVIO_ERR_INVALID; }
+    if (!n) { set_error("null count array"); return SSVIO_ERR_INVALID; }
+    if (batch < 0) { set_error("negative batch"); return SSVIO_ERR_INVALID; }
+    if (!imgs || width <= 0 || height <= 0 || batch == 0) { for (int f = 0; f < batch; ++f) n[f] = 0; h->lastBatch = 0; h->haveResults = false; return SSVIO_OK; }
+    if (stride < width * channels) { set_error("stride %d < row bytes %d", stride, width * channels); return SSVIO_ERR_INVALID; }
+    const size_t rowBytes = (size_t)width * channels;
+    int rc = orb_ensure(h, width, height, batch, channels == 3 ? (size_t)batch * rowBytes * height : 0);
+    if (rc) return rc;
+    const PyramidGeom& g = h->geom;
+    if (channels == 1) {
+        for (int f = 0; f < batch; ++f)
+            SSVIO_HIP(hipMemcpy2DAsync(h->d_pyr + (size_t)f * g.frameBytes, g.lv[0].pitch, imgs + (size_t)f * frame_stride, stride,
+                                       rowBytes, height, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int f = 0; f < batch; ++f)
+            SSVIO_HIP(hipMemcpy2DAsync(h->d_in + (size_t)f * rowBytes * height, rowBytes, imgs + (size_t)f * frame_stride, stride,
+                                       rowBytes, height, hipMemcpyHostToDevice, h->stream));
+        ProfScope p(h->prof, "k_rgb2gray", h->stream);
+        launch_rgb2gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr, g.frameBytes, g.lv[0].pitch, h->stream);
+    }
+    rc = orb_run(h, batch);
+    if (rc) return rc;
+    rc = ssvio_orb_fetch_results(h, batch, kps, desc, cap, n);
+    h->prof.resolve();
+    return rc;
+}
+
+int ssvio_orb_extract(ssvio_orb* h, const uint8_t* gray, int width, int height, int stride,
+                      ssvio_keypoint* kps, uint8_t* desc, int cap, int* n)
+{
+    return ssvio_orb_extract_batch(h, gray, 1, 1, width, height, stride, 0, kps, desc, cap, n);
+}
+
+int ssvio_orb_extract_rgb(ssvio_orb* h, const uint8_t* rgb, int width, int height, int stride,
+                          ssvio_keypoint* kps, uint8_t* desc, int cap, int* n)
+{
+    return ssvio_orb_extract_batch(h, rgb, 1, 3, width, height, stride, 0, kps, desc, cap, n);
+}
+
+int ssvio_orb_debug_level_image(ssvio_orb* h, int frame, int level, int blurred, uint8_t* dst, int dst_stride)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    if (!h->haveResults || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels || !dst) { set_error("bad frame/level or no results"); return SSVIO_ERR_INVALID; }
+    const LevelGeom& L = h->geom.lv[level];
+    if (dst_stride < L.w) { set_error("dst_stride too small"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(h->device));
+    const uint8_t* src = (blurred ? h->d_blur : h->d_pyr) + (size_t)frame * h->geom.frameBytes + L.offset;
+    SSVIO_HIP(hipMemcpy2DAsync(dst, dst_stride, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, h->stream));
+    SSVIO_HIP(hipStreamSynchronize(h->stream));
+    return SSVIO_OK;
+}
+
+static inline int refl101_host(int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p; return p; }
+
+int ssvio_orb_pyramid_level(ssvio_orb* h, int frame, int level, uint8_t* dst, int dst_stride, int* lw, int* lh)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    if (!h->haveResults || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels) { set_error("bad frame/level or no results"); return SSVIO_ERR_INVALID; }
+    const LevelGeom& L = h->geom.lv[level];
+    if (lw) *lw = L.w; if (lh) *lh = L.h;
+    if (!dst) return SSVIO_OK;
+    if (dst_stride < L.w + 2 * kEdge) { set_error("dst_stride too small"); return SSVIO_ERR_INVALID; }
+    const int rc = ssvio_orb_debug_level_image(h, frame, level, 0, dst + (size_t)kEdge * dst_stride + kEdge, dst_stride);
+    if (rc) return rc;
+    // copyMakeBorder(BORDER_REFLECT_101), src/Feature.cpp:815-821
+    for (int y = 0; y < L.h; ++y) {
+        uint8_t* row = dst + (size_t)(y + kEdge) * dst_stride + kEdge;
+        for (int i = 1; i <= kEdge; ++i) { row[-i] = row[refl101_host(-i, L.w)]; row[L.w - 1 + i] = row[refl101_host(L.w - 1 + i, L.w)]; }
+    }
+    for (int i = 1; i <= kEdge; ++i) {
+        memcpy(dst + (size_t)(kEdge - i) * dst_stride, dst + (size_t)(kEdge + refl101_host(-i, L.h)) * dst_stride, (size_t)L.w + 2 * kEdge);
+        memcpy(dst + (size_t)(kEdge + L.h - 1 + i) * dst_stride, dst + (size_t)(kEdge + refl101_host(L.h - 1 + i, L.h)) * dst_stride, (size_t)L.w + 2 * kEdge);
+    }
+    return SSVIO_OK;
+}
+
+int ssvio_orb_debug_candidates(ssvio_orb* h, int frame, int level, int32_t* xs, int32_t* ys, int32_t* resp, int cap, int* n)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    if (!h->haveResults || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels || !n) { set_error("bad frame/level or no results"); return SSVIO_ERR_INVALID; }
+    const int* cnt = h->h_candCount + frame * (kMaxLevels + 1);
+    int off = 0;
+    for (int i = 0; i < level; ++i) off += cnt[i];
+    const int c = cnt[level];
+    *n = c;
+    if (c > cap) { set_error("capacity %d < %d candidates", cap, c); return SSVIO_ERR_CAPACITY; }
+    const uint32_t* e = h->h_cand + (size_t)frame * h->candCap + off;
+    for (int i = 0; i < c; ++i) { if (xs) xs[i] = e[i] & 0xFFF; if (ys) ys[i] = (e[i] >> 12) & 0xFFF; if (resp) resp[i] = e[i] >> 24; }
+    return SSVIO_OK;
+}
+
+int ssvio_distribute_octtree(const float* xs, const float* ys, const float* resp, int n, int minX, int maxX, int minY, int maxY,
+                             int N, int32_t* out_idx, int cap, int* nout)
+{
+    if (!nout || (n > 0 && (!xs || !ys || !resp))) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    if (maxX <= minX || maxY <= minY) { set_error("empty region"); return SSVIO_ERR_INVALID; }
+    std::vector<int> out;
+    if (n > 0) { const int rc = distribute_octtree(xs, ys, resp, n, minX, maxX, minY, maxY, N, out); if (rc) return rc; }
+    *nout = (int)out.size();
+    if ((int)out.size() > cap) { set_error("capacity %d < %zu", cap, out.size()); return SSVIO_ERR_CAPACITY; }
+    for (size_t i = 0; i < out.size(); ++i) out_idx[i] = out[i];
+    return SSVIO_OK;
+}
+
+int ssvio_orb_set_profiling(ssvio_orb* h, int enable)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(h->device));
+    SSVIO_HIP(hipStreamSynchronize(h->stream));
+    h->prof.clear();
+    h->prof.enabled = enable != 0;
+    return SSVIO_OK;
+}
+
+static int prof_out(KernelProfiler& p, const char** names, double* total_ms, int32_t* launches, int cap, int* count)
+{
+    if (!count) { set_error("null count"); return SSVIO_ERR_INVALID; }
+    p.resolve();
+    const int n = (int)p.stats.size();
+    *count = n;
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (names) names[i] = p.stats[i].name;
+        if (total_ms) total_ms[i] = p.stats[i].ms;
+        if (launches) launches[i] = p.stats[i].launches;
+    }
+    return SSVIO_OK;
+}
+
+int ssvio_orb_kernel_times(ssvio_orb* h, const char** names, double* total_ms, int32_t* launches, int cap, int* count)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(h->device));
+    SSVIO_HIP(hipStreamSynchronize(h->stream));
+    return prof_out(h->prof, names, total_ms, launches, cap, count);
+}
+
+int ssvio_orb_set_stream(ssvio_orb* h, void* hip_stream)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(h->device));
+    SSVIO_HIP(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own;
+    return SSVIO_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================
+struct ssvio_matcher {
+    int device = 0;
+    int threshold = 50; float nnRatio = 0.6f;
+    hipStream_t own = nullptr, stream = nullptr;
+    uint8_t* d_q = nullptr; size_t qRows = 0;
+    uint8_t* d_t = nullptr; size_t tRows = 0;
+    int* d_counts2 = nullptr;            // {nq, nt} of the single-pair entry points
+    uint2* d_partial = nullptr; size_t partialCap = 0;
+    uint2* d_partialRev = nullptr; size_t partialRevCap = 0;
+    ssvio_dmatch* d_out = nullptr; size_t outCap = 0;
+    int32_t* d_raw = nullptr; size_t rawCap = 0;
+    int* d_nout = nullptr; size_t noutCap = 0;
+    int* d_pairs = nullptr; size_t pairsCap = 0;
+    KernelProfiler prof;
+    int lastPairs = 0, lastMaxRows = 0;
+};
+
+template <typename T> static int grow(T*& p, size_t& cap, size_t need, hipStream_t s)
+{
+    if (need <= cap) return SSVIO_OK;
+    SSVIO_HIP(hipStreamSynchronize(s));
+    dfree(p);
+    need += need / 4;
+    SSVIO_HIP(hipMalloc(&p, need * sizeof(T)));
+    cap = need;
+    return SSVIO_OK;
+}
+
+static int mt_check(ssvio_matcher* m) { if (!m) { set_error("null matcher handle"); return SSVIO_ERR_INVALID; } return SSVIO_OK; }
+
+// choose how many pieces the train set is cut into so that the launch has >= ~1024 workgroups
+static void pick_chunks(int maxQ, int maxT, int npairs, int& nChunks, int& chunkRows)
+{
+    const int R = maxQ > 2048 ? 4 : maxQ > 512 ? 2 : 1;
+    const long qBlocks = (long)((maxQ + 256 * R - 1) / (256 * R)) * npairs;
+    long want = (1024 + qBlocks - 1) / qBlocks;
+    const long maxChunks = std::max(1, (maxT + 127) / 128);
+    want = std::min<long>(std::min<long>(want, maxChunks), 64);
+    nChunks = (int)std::max<long>(want, 1);
+    chunkRows = ((maxT + nChunks - 1) / nChunks + 127) / 128 * 128;
+    nChunks = std::max(1, (maxT + chunkRows - 1) / chunkRows);
+}
+
+// shared driver: descriptors on the device; pairs == nullptr means the single pair (0,0)
+static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
+                     const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts,
+                     const int* d_pairs, int npairs, int maxQ, int maxT, int mode)
+{
+    hipStream_t s = m->stream;
+    const int maxRows = std::max(maxQ, maxT);
+    int nChunks, chunkRows;
+    pick_chunks(maxQ, maxT, npairs, nChunks, chunkRows);
+    int rc = grow(m->d_partial, m->partialCap, (size_t)npairs * nChunks * maxRows, s); if (rc) return rc;
+    rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
+    if (mode == 3) { rc = grow(m->d_raw, m->rawCap, (size_t)npairs * 3 * maxRows, s); if (rc) return rc; }
+    else { rc = grow(m->d_out, m->outCap, (size_t)npairs * maxRows, s); if (rc) return rc; }
+    MatchArgs a{};
+    a.qdesc = (const uint4*)d_qdesc; a.tdesc = (const uint4*)d_tdesc;
+    a.qSetStrideRows = qStrideRows; a.tSetStrideRows = tStrideRows;
+    a.qcounts = d_qcounts; a.tcounts = d_tcounts; a.pairs = d_pairs; a.swap = 0;
+    a.nChunks = nChunks; a.chunkRows = chunkRows; a.partial = m->d_partial; a.maxRows = maxRows;
+    {
+        ProfScope p(m->prof, "k_hamming_knn2", s);
+        launch_knn2(a, maxQ, npairs, s);
+    }
+    FinalizeArgs f{};
+    f.partial = m->d_partial; f.nChunks = nChunks; f.maxRows = maxRows;
+    f.qcounts = d_qcounts; f.tcounts = d_tcounts; f.pairs = d_pairs;
+    f.mode = mode; f.threshold = m->threshold; f.nnRatio = m->nnRatio;
+    f.out = m->d_out; f.nout = m->d_nout; f.raw = m->d_raw;
+    if (mode == SSVIO_MODE_CROSSCHECK) {
+        int nChunksR, chunkRowsR;
+        pick_chunks(maxT, maxQ, npairs, nChunksR, chunkRowsR);
+        rc = grow(m->d_partialRev, m->partialRevCap, (size_t)npairs * nChunksR * maxRows, s); if (rc) return rc;
+        MatchArgs r = a;
+        r.qdesc = (const uint4*)d_tdesc; r.tdesc = (const uint4*)d_qdesc;
+        r.qSetStrideRows = tStrideRows; r.tSetStrideRows = qStrideRows;
+        r.qcounts = d_tcounts; r.tcounts = d_qcounts; r.swap = 1;
+        r.nChunks = nChunksR; r.chunkRows = chunkRowsR; r.partial = m->d_partialRev;
+        {
+            ProfScope p(m->prof, "k_hamming_knn2", s);
+            launch_knn2(r, maxT, npairs, s);
+        }
+        f.partialRev = m->d_partialRev; f.nChunksRev = nChunksR;
+    }
+    {
+        ProfScope p(m->prof, "k_match_finalize", s);
+        launch_finalize(f, npairs, s);
+    }
+    m->lastPairs = npairs; m->lastMaxRows = maxRows;
+    return SSVIO_OK;
+}
+
+// host-pointer single pair
+static int match_host(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, int mode,
+                      ssvio_dmatch* out, int cap, int* n, int32_t* idx, int32_t* d1, int32_t* d2)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (nq < 0 || nt < 0) { set_error("negative row count"); return SSVIO_ERR_INVALID; }
+    if (n) *n = 0;
+    if (!(nq > 0 && nt > 0)) return SSVIO_OK;                          // src/FeatureMatching.cpp:25-27
+    if (!q || !t) { set_error("null descriptor pointer"); return SSVIO_ERR_INVALID; }
+    if (qstride < 32 || tstride < 32) { set_error("descriptor stride < 32"); return SSVIO_ERR_INVALID; }
+    if (nt > (1 << 23) || nq > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
+    if (mode != 3 && cap < nq) { set_error("output capacity %d < %d query rows", cap, nq); return SSVIO_ERR_CAPACITY; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
+    int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
+    rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
+    SSVIO_HIP(hipMemcpy2DAsync(m->d_q, 32, q, qstride, 32, nq, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpy2DAsync(m->d_t, 32, t, tstride, 32, nt, hipMemcpyHostToDevice, s));
+    const int counts[2] = {nq, nt};
+    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipStreamSynchronize(s));                                // `counts` is a stack array
+    rc = match_run(m, m->d_q, 0, m->d_counts2, m->d_t, 0, m->d_counts2 + 1, nullptr, 1, nq, nt, mode);
+    if (rc) return rc;
+    const int maxRows = std::max(nq, nt);
+    if (mode == 3) {
+        std::vector<int32_t> raw((size_t)3 * maxRows);
+        SSVIO_HIP(hipMemcpyAsync(raw.data(), m->d_raw, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < nq; ++i) { if (idx) idx[i] = raw[i]; if (d1) d1[i] = raw[maxRows + i]; if (d2) d2[i] = raw[2 * (size_t)maxRows + i]; }
+    } else {
+        int cnt = 0;
+        SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipStreamSynchronize(s));
+        if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+        if (n) *n = cnt;
+    }
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+extern "C" {
+
+int ssvio_matcher_create(int threshold, float nn_ratio, int device, ssvio_matcher** out)
+{
+    if (!out) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    *out = nullptr;
+    const int rc = pick_device(device);
+    if (rc) return rc;
+    SSVIO_HIP(hipSetDevice(device));
+    ssvio_matcher* m = new ssvio_matcher();
+    m->device = device; m->threshold = threshold; m->nnRatio = nn_ratio;
+    if (hipStreamCreateWithFlags(&m->own, hipStreamNonBlocking) != hipSuccess || hipMalloc(&m->d_counts2, 2 * sizeof(int)) != hipSuccess) {
+        set_error("cannot create HIP stream / allocate"); delete m; return SSVIO_ERR_HIP;
+    }
+    m->stream = m->own;
+    *out = m;
+    return SSVIO_OK;
+}
+
+void ssvio_matcher_destroy(ssvio_matcher* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    m->prof.resolve(); m->prof.destroy();
+    dfree(m->d_q); dfree(m->d_t); dfree(m->d_counts2); dfree(m->d_partial); dfree(m->d_partialRev);
+    dfree(m->d_out); dfree(m->d_raw); dfree(m->d_nout); dfree(m->d_pairs);
+    if (m->own) (void)hipStreamDestroy(m->own);
+    delete m;
+}
+
+int ssvio_matcher_set_stream(ssvio_matcher* m, void* hip_stream)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(m->device));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    m->stream = hip_stream ? (hipStream_t)hip_stream : m->own;
+    return SSVIO_OK;
+}
+
+int ssvio_matcher_set_profiling(ssvio_matcher* m, int enable)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(m->device));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    m->prof.clear();
+    m->prof.enabled = enable != 0;
+    return SSVIO_OK;
+}
+
+int ssvio_matcher_kernel_times(ssvio_matcher* m, const char** names, double* total_ms, int32_t* launches, int cap, int* count)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(m->device));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    return prof_out(m->prof, names, total_ms, launches, cap, count);
+}
+
+int ssvio_match_bruteforce(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
+                           ssvio_dmatch* out, int cap, int* n)
+{ return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_BRUTEFORCE, out, cap, n, nullptr, nullptr, nullptr); }
+
+int ssvio_match_knn2_ratio(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
+                           ssvio_dmatch* out, int cap, int* n)
+{ return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_KNN2_RATIO, out, cap, n, nullptr, nullptr, nullptr); }
+
+int ssvio_match_crosscheck(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
+                           ssvio_dmatch* out, int cap, int* n)
+{ return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_CROSSCHECK, out, cap, n, nullptr, nullptr, nullptr); }
+
+int ssvio_match_knn2_raw(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
+                         int32_t* idx, int32_t* d1, int32_t* d2)
+{ return match_host(m, q, nq, qstride, t, nt, tstride, 3, nullptr, 0, nullptr, idx, d1, d2); }
+
+int ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_rows, int max_rows, const int32_t* d_counts,
+                          const int32_t* pairs, int npairs, int mode, const void** d_matches, const int32_t** d_nmatches)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (!d_desc || !d_counts || !pairs || npairs <= 0 || max_rows <= 0 || set_stride_rows < max_rows) { set_error("bad batch arguments"); return SSVIO_ERR_INVALID; }
+    if (mode < 0 || mode > 2) { set_error("mode must be 0..2"); return SSVIO_ERR_INVALID; }
+    if (max_rows > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    int rc = grow(m->d_pairs, m->pairsCap, (size_t)npairs * 2, m->stream); if (rc) return rc;
+    SSVIO_HIP(hipMemcpyAsync(m->d_pairs, pairs, (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));        // pairs may be pageable caller memory
+    rc = match_run(m, (const uint8_t*)d_desc, set_stride_rows, d_counts, (const uint8_t*)d_desc, set_stride_rows, d_counts,
+                   m->d_pairs, npairs, max_rows, max_rows, mode);
+    if (rc) return rc;
+    if (d_matches) *d_matches = m->d_out;
+    if (d_nmatches) *d_nmatches = m->d_nout;
+    return SSVIO_OK;
+}
+
+int ssvio_matcher_sync(ssvio_matcher* m)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(m->device));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_match_batch_fetch(ssvio_matcher* m, int npairs, int max_rows, ssvio_dmatch* out, int32_t* n)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (npairs != m->lastPairs || max_rows != m->lastMaxRows || !n) { set_error("fetch does not match the last batch call"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    SSVIO_HIP(hipMemcpyAsync(n, m->d_nout, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if (out) SSVIO_HIP(hipMemcpyAsync(out, m->d_out, (size_t)npairs * max_rows * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost, m->stream));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    return SSVIO_OK;
+}
+
+}  // extern "C"

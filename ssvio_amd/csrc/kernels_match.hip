@@ -1,0 +1,197 @@
+// kernels_match.hip -- brute-force Hamming 2-NN on gfx950 and the match filters.
+//
+// k_hamming_knn2: each lane keeps R query descriptors (8 dwords each) in VGPRs; the train
+// descriptors of the block's chunk stream through LDS in 4-KB tiles and are read back as
+// wave-wide broadcasts (2 x ds_read_b128 per train row); per (query, train): 8 v_xor +
+// 8 accumulating v_bcnt_u32_b32 + pack + v_med3/v_min on the key (dist << 23 | trainIdx),
+// so the two smallest keys are exactly ComputeMatchingScore + the best/second-best loop of
+// src/FeatureMatching.cpp:85-102,211-228 with lowest-index ties.  No MFMA: the path is
+// integer xor/popcount, VALU-bound.
+#include "match.h"
+
+namespace ssvio {
+
+constexpr int kTT = 128;                 // train rows per LDS tile
+constexpr unsigned kKeyInit = 0xFFFFFFFFu;
+
+// median of three unsigned values in one VALU instruction
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
+{
+    __shared__ uint4 tile[kTT * 2];
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.z, chunk = blockIdx.y;
+    const int qset = a.pairs ? a.pairs[2 * pair + a.swap] : 0;
+    const int tset = a.pairs ? a.pairs[2 * pair + 1 - a.swap] : 0;
+    const int nq = a.qcounts[qset], nt = a.tcounts[tset];
+    const int qtile = blockIdx.x * 256 * R;
+    if (qtile >= nq) return;                                   // block-uniform
+    const uint4* Q = a.qdesc + (size_t)qset * a.qSetStrideRows * 2;
+    const uint4* T = a.tdesc + (size_t)tset * a.tSetStrideRows * 2;
+    const int cBegin = chunk * a.chunkRows, cEnd = min(nt, cBegin + a.chunkRows);
+
+    uint32_t q[R][8], k1[R], k2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int qi = qtile + r * 256 + tid;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if (qi < nq) { lo = Q[(size_t)qi * 2]; hi = Q[(size_t)qi * 2 + 1]; }
+        q[r][0] = lo.x; q[r][1] = lo.y; q[r][2] = lo.z; q[r][3] = lo.w;
+        q[r][4] = hi.x; q[r][5] = hi.y; q[r][6] = hi.z; q[r][7] = hi.w;
+        k1[r] = kKeyInit; k2[r] = kKeyInit;
+    }
+    for (int t0 = cBegin; t0 < cEnd; t0 += kTT) {
+        __syncthreads();
+        const int rows = min(kTT, cEnd - t0);
+        if (tid < rows * 2) tile[tid] = T[(size_t)t0 * 2 + tid];
+        __syncthreads();
+#pragma unroll 2
+        for (int j = 0; j < rows; ++j) {
+            const uint4 lo = tile[2 * j], hi = tile[2 * j + 1];
+            const uint32_t idx = (uint32_t)(t0 + j);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                uint32_t d = __popc(q[r][0] ^ lo.x);
+                d += __popc(q[r][1] ^ lo.y); d += __popc(q[r][2] ^ lo.z); d += __popc(q[r][3] ^ lo.w);
+                d += __popc(q[r][4] ^ hi.x); d += __popc(q[r][5] ^ hi.y); d += __popc(q[r][6] ^ hi.z); d += __popc(q[r][7] ^ hi.w);
+                const uint32_t key = (d << 23) | idx;
+                k2[r] = umed3(k1[r], k2[r], key);     // second smallest of {k1,k2,key}, k1 <= k2
+                k1[r] = min(k1[r], key);
+            }
+        }
+    }
+    uint2* out = a.partial + ((size_t)pair * a.nChunks + chunk) * a.maxRows;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int qi = qtile + r * 256 + tid;
+        if (qi < nq) out[qi] = make_uint2(k1[r], k2[r]);
+    }
+}
+
+void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s)
+{
+    // R = 4 keeps LDS reads at a quarter of the VALU time; small query sets use R = 1 so that
+    // more workgroups exist.
+    if (maxQ > 2048) {
+        dim3 grid((maxQ + 1023) / 1024, a.nChunks, npairs);
+        hipLaunchKernelGGL(k_hamming_knn2<4>, grid, dim3(256), 0, s, a);
+    } else if (maxQ > 512) {
+        dim3 grid((maxQ + 511) / 512, a.nChunks, npairs);
+        hipLaunchKernelGGL(k_hamming_knn2<2>, grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((maxQ + 255) / 256, a.nChunks, npairs);
+        hipLaunchKernelGGL(k_hamming_knn2<1>, grid, dim3(256), 0, s, a);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// merge the chunks' two smallest keys
+__device__ __forceinline__ void merge_chunks(const uint2* __restrict__ partial, int nChunks, int maxRows, int i,
+                                             uint32_t& k1, uint32_t& k2)
+{
+    k1 = kKeyInit; k2 = kKeyInit;
+    for (int c = 0; c < nChunks; ++c) {
+        const uint2 p = partial[(size_t)c * maxRows + i];
+        k2 = umed3(k1, k2, p.x); k1 = min(k1, p.x);
+        k2 = umed3(k1, k2, p.y); k1 = min(k1, p.y);
+    }
+}
+
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int base = 0; total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (i < wid) base += wsum[i]; total += wsum[i]; }
+    return base + incl - v;
+}
+
+// one workgroup per pair: filter and emit DMatch rows in ascending query order.
+//   mode 0: MatchByBruteForce (src/FeatureMatching.cpp:35-54): keep d < max(2*min_d, 30)
+//   mode 1: Threshold / NNRatio acceptance (src/FeatureMatching.cpp:104-111)
+//   mode 2: mutual nearest neighbour
+//   mode 3: raw (idx, d1, d2) triples, no filtering
+__global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
+{
+    __shared__ int wsum[4];
+    __shared__ int sMin;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int qset = a.pairs ? a.pairs[2 * pair] : 0;
+    const int tset = a.pairs ? a.pairs[2 * pair + 1] : 0;
+    const int nq = a.qcounts[qset], nt = a.tcounts[tset];
+    const uint2* P = a.partial + (size_t)pair * a.nChunks * a.maxRows;
+    const uint2* PR = a.partialRev ? a.partialRev + (size_t)pair * a.nChunksRev * a.maxRows : nullptr;
+    ssvio_dmatch* out = a.out ? a.out + (size_t)pair * a.maxRows : nullptr;
+    if (nq <= 0 || nt <= 0) { if (tid == 0 && a.nout) a.nout[pair] = 0; return; }   // src/FeatureMatching.cpp:25-27
+
+    if (a.mode == 3) {
+        int32_t* raw = a.raw + (size_t)pair * a.maxRows * 3;
+        for (int i = tid; i < nq; i += 256) {
+            uint32_t k1, k2; merge_chunks(P, a.nChunks, a.maxRows, i, k1, k2);
+            const int d1 = min((int)(k1 >> 23), 256), d2 = min((int)(k2 >> 23), 256);
+            raw[i] = d1 < 256 ? (int)(k1 & 0x7FFFFF) : -1;       // 'dist < bestDist1' with bestDist1 = 256 never fires for 256
+            raw[a.maxRows + i] = d1; raw[2 * a.maxRows + i] = d2;
+        }
+        return;
+    }
+    int minD = 1 << 20;
+    if (a.mode == 0) {
+        if (tid == 0) sMin = 1 << 20;
+        __syncthreads();
+        for (int i = tid; i < nq; i += 256) {
+            uint32_t k1, k2; merge_chunks(P, a.nChunks, a.maxRows, i, k1, k2);
+            minD = min(minD, (int)(k1 >> 23));
+        }
+        atomicMin(&sMin, minD);
+        __syncthreads();
+        minD = sMin;
+    }
+    const int lim = max(2 * minD, 30);
+    int written = 0;
+    for (int i0 = 0; i0 < nq; i0 += 256) {
+        const int i = i0 + tid;
+        bool keep = false; uint32_t k1 = kKeyInit, k2 = kKeyInit;
+        if (i < nq) {
+            merge_chunks(P, a.nChunks, a.maxRows, i, k1, k2);
+            const int d1 = (int)(k1 >> 23), d2 = min((int)(k2 >> 23), 256);
+            if (a.mode == 0) keep = d1 < lim;
+            else if (a.mode == 1) keep = d1 <= a.threshold && (float)d1 < a.nnRatio * (float)d2;
+            else {
+                uint32_t r1, r2; merge_chunks(PR, a.nChunksRev, a.maxRows, (int)(k1 & 0x7FFFFF), r1, r2);
+                keep = (int)(r1 & 0x7FFFFF) == i;
+            }
+        }
+        int total;
+        const int off = block_excl_scan(keep ? 1 : 0, wsum, total);
+        if (keep) {
+            ssvio_dmatch m;
+            const int d1 = (int)(k1 >> 23);
+            m.queryIdx = i; m.imgIdx = a.mode == 1 ? -1 : 0; m.distance = (float)d1;
+            // :94 'dist < bestDist1' never fires at 256, so the 2-NN loop leaves bestIdx = -1 there; BFMatcher keeps the row
+            m.trainIdx = (a.mode == 1 && d1 >= 256) ? -1 : (int)(k1 & 0x7FFFFF);
+            out[written + off] = m;
+        }
+        written += total;
+    }
+    if (tid == 0) a.nout[pair] = written;
+}
+
+void launch_finalize(const FinalizeArgs& a, int npairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_match_finalize, dim3(npairs), dim3(256), 0, s, a);
+}
+
+}  // namespace ssvio

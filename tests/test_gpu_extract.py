@@ -1,0 +1,135 @@
+"""GPU parity: ORB extraction through the C ABI vs the CPU oracle, stage by stage and end to end.
+Bar: bit-exact for every integer output (pyramid bytes, FAST candidates, blurred bytes, keypoint
+coordinates/levels/responses, descriptors) and -- because both sides run the same IEEE sequence --
+bit-exact float angles as well (the north-star tolerance for angles is 1e-4 relative)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import ssvio_amd
+    from ssvio_amd import synth
+    from oracle import oracle as O
+    return ssvio_amd, synth, O
+
+
+def _cmp_frame(O, ex_gpu, ex_cpu, img, kps, desc):
+    rk, rd = ex_cpu.extract(img)
+    assert len(kps) == len(rk)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(kps[f], rk[f]), f
+    assert np.array_equal(kps["angle"].view(np.uint32), rk["angle"].view(np.uint32)), "angle bits"
+    assert np.array_equal(desc, rd)
+    return rk, rd
+
+
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (640, 480, 500), (320, 240, 1200), (601, 397, 700)])
+def test_stages_and_end_to_end(mods, w, h, nf):
+    S, synth, O = mods
+    img = synth.texture(7 + w, h, w)
+    g = S.ORBextractor(nf, 1.2, 8, 20, 7)
+    c = O.Extractor(nf, 1.2, 8, 20, 7)
+    kps, desc = g.Extract(img)
+    _cmp_frame(O, g, c, img, kps, desc)
+    assert len(kps) > nf // 2
+    for l in range(8):
+        assert np.array_equal(g.debug_level_image(l), c.level_image(l)), "pyramid level %d" % l
+        xs, ys, rs = g.debug_candidates(l)
+        cx, cy, cr = c.level_candidates(l)
+        assert np.array_equal(xs, cx.astype(np.int32)) and np.array_equal(ys, cy.astype(np.int32)), "FAST corners level %d" % l
+        assert np.array_equal(rs, cr.astype(np.int32)), "FAST scores level %d" % l
+        b = c.level_blur(l)
+        if b is not None:
+            assert np.array_equal(g.debug_level_image(l, blurred=True), b), "blur level %d" % l
+    g.close()
+
+
+def test_tables_match_oracle(mods):
+    S, synth, O = mods
+    for nf, sf, nl in [(1200, 1.2, 8), (500, 1.2, 8), (4000, 1.2, 8), (1000, 1.5, 5), (777, 1.1, 12)]:
+        g = S.ORBextractor(nf, sf, nl, 20, 7); c = O.Extractor(nf, sf, nl, 20, 7)
+        assert np.array_equal(g.GetScaleFactors(), c.scale_factors())
+        assert np.array_equal(g.GetInvScaleFactor(), c.inv_scale_factors())
+        assert np.array_equal(g.GetLevelSigmaSquares(), c.level_sigma2())
+        assert np.array_equal(g.GetInvLevelSigmaSquares(), c.inv_level_sigma2())
+        assert np.array_equal(g.features_per_level(), c.features_per_level())
+        assert g.GetLevels() == nl
+        g.close()
+
+
+def test_rgb_frame_ctor(mods):
+    S, synth, O = mods
+    gray = synth.texture(21, 240, 320)
+    rgb = synth.to_rgb(gray, 3)
+    g = S.ORBextractor(1200, 1.2, 8, 20, 7); c = O.Extractor(1200, 1.2, 8, 20, 7)
+    kps, desc = g.ExtractRGB(rgb)
+    rk, rd = c.extract_rgb(rgb)
+    assert len(kps) == len(rk) and np.array_equal(desc, rd)
+    assert np.array_equal(g.debug_level_image(0), O.rgb2gray(rgb))
+    assert np.array_equal(kps.view(np.uint8), rk.view(np.uint8))
+    g.close()
+
+
+def test_batch_equals_singles_and_stream(mods):
+    S, synth, O = mods
+    frames = synth.frame_stream(5, 6)
+    g = S.ORBextractor(1000, 1.2, 8, 20, 7); c = O.Extractor(1000, 1.2, 8, 20, 7)
+    kps, desc, n = g.extract_batch(frames)
+    for f in range(len(frames)):
+        rk, rd = c.extract(frames[f])
+        assert n[f] == len(rk)
+        assert np.array_equal(kps[f, :n[f]].view(np.uint8), rk.view(np.uint8)), "frame %d keypoints" % f
+        assert np.array_equal(desc[f, :n[f]], rd), "frame %d descriptors" % f
+    # a second call with a smaller batch and the single-frame entry point reuse the same handle
+    k1, d1 = g.Extract(frames[2])
+    assert np.array_equal(d1, desc[2, :n[2]])
+    g.close()
+
+
+def test_low_texture_min_threshold_fallback(mods):
+    """cells whose FAST(20) list is empty are retried at 7 (src/Feature.cpp:875-879)"""
+    S, synth, O = mods
+    img = (synth.texture(33, 480, 640).astype(np.float32) * 0.12 + 100).astype(np.uint8)   # low contrast
+    g = S.ORBextractor(1000, 1.2, 8, 20, 7); c = O.Extractor(1000, 1.2, 8, 20, 7)
+    kps, desc = g.Extract(img)
+    rk, rd = _cmp_frame(O, g, c, img, kps, desc)
+    assert (rk["response"] < 20).any(), "fixture must exercise the minThFAST path"
+    g.close()
+
+
+def test_flat_and_empty_inputs(mods):
+    S, synth, O = mods
+    g = S.ORBextractor(1000, 1.2, 8, 20, 7)
+    kps, desc = g.Extract(np.full((480, 640), 77, np.uint8))        # no corners at all -> 0 keypoints, descriptors released
+    assert len(kps) == 0 and desc.shape == (0, 32)
+    kps, desc = g.Extract(np.zeros((0, 0), np.uint8))               # empty image: silent return (src/Feature.cpp:507)
+    assert len(kps) == 0
+    with pytest.raises(AssertionError):
+        g.Extract(np.zeros((480, 640), np.float32))                 # assert(type == CV_8UC1) (src/Feature.cpp:511)
+    with pytest.raises(S.SsvioError) as e:
+        g.Extract(np.zeros((100, 100), np.uint8))                   # top levels smaller than one FAST cell
+    assert e.value.code == -4
+    g.close()
+
+
+def test_mvImagePyramid_has_reflect101_rim(mods):
+    S, synth, O = mods
+    img = synth.texture(9, 240, 320)
+    g = S.ORBextractor(500, 1.2, 8, 20, 7); c = O.Extractor(500, 1.2, 8, 20, 7)
+    g.Extract(img); c.extract(img)
+    pyr = g.image_pyramid()
+    for l in range(8):
+        assert np.array_equal(pyr[l], O.border_reflect101(c.level_image(l), 19))
+    g.close()
+
+
+def test_1080p_4000_features(mods):
+    S, synth, O = mods
+    img = synth.texture(101, 1080, 1920)
+    g = S.ORBextractor(4000, 1.2, 8, 20, 7); c = O.Extractor(4000, 1.2, 8, 20, 7)
+    kps, desc = g.Extract(img)
+    _cmp_frame(O, g, c, img, kps, desc)
+    g.close()

@@ -1,0 +1,107 @@
+"""GPU parity: brute-force Hamming matching through the C ABI vs the CPU oracle.  Integer
+work: bit-exact indices, distances and DMatch rows, lowest-index tie-breaking."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import ssvio_amd
+    from ssvio_amd import synth
+    from oracle import oracle as O
+    return ssvio_amd, synth, O
+
+
+@pytest.fixture(scope="module")
+def fm(mods):
+    S, _, _ = mods
+    m = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 300), (300, 1), (255, 257), (500, 500), (1000, 1010), (4000, 4000), (2049, 777)])
+def test_all_modes_match_oracle(mods, fm, nq, nt):
+    S, synth, O = mods
+    q, t = synth.descriptor_sets(nq * 31 + nt, nq, nt)
+    idx, d1, d2 = fm.knn2_raw(q, t)
+    ri, r1, r2 = O.knn2_raw(q, t)
+    assert np.array_equal(idx, ri) and np.array_equal(d1, r1) and np.array_equal(d2, r2)
+    ok, m = fm.MatchByBruteForce(q, t)
+    assert np.array_equal(m.view(np.uint8), O.match_bruteforce(q, t).view(np.uint8)) and ok == (len(m) > 0)
+    ok, m = fm.MatchByKnnRatio(q, t)
+    assert np.array_equal(m.view(np.uint8), O.match_knn2_ratio(q, t, 50, 0.6).view(np.uint8))
+    ok, m = fm.MatchByCrossCheck(q, t)
+    assert np.array_equal(m.view(np.uint8), O.match_crosscheck(q, t).view(np.uint8))
+
+
+def test_ties_resolve_to_lowest_index(mods, fm):
+    S, synth, O = mods
+    q, t = synth.descriptor_sets(5, 64, 40)
+    t = np.concatenate([t, t, t[:7]])          # every train row appears 2-3 times
+    q[:10] = t[5:15]                           # exact matches, duplicated later
+    idx, d1, d2 = fm.knn2_raw(q, t)
+    ri, r1, r2 = O.knn2_raw(q, t)
+    assert np.array_equal(idx, ri) and np.array_equal(d1, r1) and np.array_equal(d2, r2)
+    assert (d1[:10] == 0).all() and (d2[:10] == 0).all() and (idx[:10] == np.arange(5, 15)).all()
+    for a, b in ((fm.MatchByBruteForce(q, t)[1], O.match_bruteforce(q, t)), (fm.MatchByCrossCheck(q, t)[1], O.match_crosscheck(q, t))):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_distance_256_and_filter_boundaries(mods, fm):
+    S, synth, O = mods
+    q = np.zeros((4, 32), np.uint8); t = np.full((3, 32), 255, np.uint8)     # every pair at distance 256
+    idx, d1, d2 = fm.knn2_raw(q, t)
+    assert (idx == -1).all() and (d1 == 256).all() and (d2 == 256).all()      # 'dist < 256' never fires (:94)
+    ok, m = fm.MatchByBruteForce(q, t)                                         # BFMatcher still reports index 0
+    r = O.match_bruteforce(q, t)
+    assert np.array_equal(m.view(np.uint8), r.view(np.uint8)) and (m["trainIdx"] == 0).all() and len(m) == 4
+    # filter boundary of src/FeatureMatching.cpp:49: keep dist < max(2*min, 30), strict
+    t = np.zeros((1, 32), np.uint8)
+    q = np.zeros((4, 32), np.uint8)
+    def setbits(row, n):
+        bits = np.zeros(256, np.uint8); bits[:n] = 1
+        q[row] = np.packbits(bits, bitorder="little")
+    setbits(0, 10); setbits(1, 29); setbits(2, 30); setbits(3, 31)             # min = 10 -> limit 30
+    ok, m = fm.MatchByBruteForce(q, t)
+    assert list(m["queryIdx"]) == [0, 1] and list(m["distance"]) == [10.0, 29.0]
+    setbits(0, 16)                                                             # min = 16 -> limit 32
+    ok, m = fm.MatchByBruteForce(q, t)
+    assert list(m["queryIdx"]) == [0, 1, 2, 3]
+    assert np.array_equal(m.view(np.uint8), O.match_bruteforce(q, t).view(np.uint8))
+
+
+def test_empty_sets_and_strided_rows(mods, fm):
+    S, synth, O = mods
+    q, t = synth.descriptor_sets(9, 100, 120)
+    e = np.zeros((0, 32), np.uint8)
+    for a, b in ((e, t), (q, e), (e, e)):
+        ok, m = fm.MatchByBruteForce(a, b)
+        assert ok is False and len(m) == 0                                      # src/FeatureMatching.cpp:25-27
+    big = np.zeros((100, 64), np.uint8); big[:, :32] = q                       # non-continuous Mat rows
+    ok, m = fm.MatchByBruteForce(big[:, :32], t)
+    assert np.array_equal(m.view(np.uint8), O.match_bruteforce(q, t).view(np.uint8))
+
+
+def test_threshold_and_ratio_parameters(mods):
+    S, synth, O = mods
+    q, t = synth.descriptor_sets(77, 600, 650)
+    for th, ratio in ((50, 0.6), (30, 0.9), (256, 1.5), (0, 0.5)):
+        m = S.FeatureMatching(None, {"Threshold": th, "NNRatio": ratio})
+        ok, got = m.MatchByKnnRatio(q, t)
+        assert np.array_equal(got.view(np.uint8), O.match_knn2_ratio(q, t, th, ratio).view(np.uint8)), (th, ratio)
+        m.close()
+
+
+def test_match_real_descriptors_frame_pair(mods, fm):
+    """BASELINE config 1: frame pair, 500 features, MatchByBruteForce(descB, descA)"""
+    S, synth, O = mods
+    a, b = synth.frame_pair(3)
+    g = S.ORBextractor(500, 1.2, 8, 20, 7)
+    ka, da = g.Extract(a); kb, db = g.Extract(b)
+    ok, m = fm.MatchByBruteForce(db, da)
+    assert ok and np.array_equal(m.view(np.uint8), O.match_bruteforce(db, da).view(np.uint8))
+    assert len(m) > 50
+    g.close()
