@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE config 2 on MI355X: VGA stream, 1000 features/frame, per-frame ORB
+extraction + MatchByBruteForce against the previous frame.
+
+A step = one batch of `--batch` synthetic VGA frames already resident in HBM:
+extract_batch_dev (pyramid, FAST cells, quadtree, blur, IC angle + rBRIEF) followed by one
+batched brute-force match launch (frame f vs frame f-1; frame 0 wraps to the batch's last frame
+so every frame is matched once).  value = frames/s over all ranks.  With --gpus N every rank
+runs the same workload on its own frames (frames are independent units: weak scaling, no
+data-path collective); the per-rank frame counts are gathered once at the end.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest share of GPU time
+in the timed region, measured with hipEvent pairs on the library's stream; `cpu_baseline` is the
+CPU oracle (oracle/, a port of the reference algorithm) timed single-threaded on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6e12 int lane-ops/s
+
+
+def level_pixels(ex, w, h):
+    return [ex.level_geometry(w, h, l)["w"] * ex.level_geometry(w, h, l)["h"] for l in range(ex.nlevels)]
+
+
+def algorithmic_bytes(kernel, B, px, nkp_total, pairs_rows):
+    """SURVEY.md §8(d) per-unit figures split per kernel; bytes for ONE launch over the batch."""
+    P = sum(px)
+    if kernel == "k_fast_cells":
+        return B * P                                   # every pyramid pixel read once
+    if kernel == "k_blur":
+        return B * 2 * P                               # read level, write blurred level
+    if kernel == "k_resize":
+        # 7 launches per step; average launch: read level l-1, write level l
+        return B * (sum(px[:-1]) + sum(px[1:])) / max(len(px) - 1, 1)
+    if kernel == "k_describe":
+        return nkp_total * (600 + 512 + 60)            # IC patch + rBRIEF samples read, keypoint+descriptor written
+    if kernel in ("k_copy_gray", "k_rgb2gray"):
+        return B * 2 * px[0]
+    if kernel == "k_compact":
+        return nkp_total * 8 * 6                       # ~6 candidates per kept keypoint, read + write 4 B
+    if kernel == "k_hamming_knn2":
+        return sum(32 * (nq + nt) + 16 * nq for nq, nt in pairs_rows)
+    if kernel == "k_match_finalize":
+        return sum(8 * nq + 16 * nq for nq, nt in pairs_rows)
+    return 0
+
+
+def cpu_baseline(frames, nfeatures, budget_s=12.0):
+    """oracle extract + BF match vs previous frame, 1 thread, bounded sample of the same frames"""
+    from oracle import oracle as O
+    ex = O.Extractor(nfeatures, 1.2, 8, 20, 7)
+    prev = None
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        f = frames[n % len(frames)]
+        k, d = ex.extract(f)
+        if prev is not None:
+            O.match_bruteforce(d, prev)
+        prev = d
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 4 * len(frames):
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d VGA frames (extract %d features + BF match vs previous), oracle C restatement, 1 thread, %.1f s" % (n, nfeatures, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--features", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import ssvio_amd
+    from ssvio_amd import synth, _lib as L
+
+    B, W, H = args.batch, args.width, args.height
+    frames = synth.frame_stream(1000 + rank, B, H, W)            # seeded, per-rank stream
+    d_frames = torch.from_numpy(frames).to(dev)
+    ex = ssvio_amd.ORBextractor(args.features, 1.2, 8, 20, 7, device=dev.index)
+    fm = ssvio_amd.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6}, device=dev.index)
+    pairs = np.array([[f, (f - 1) % B] for f in range(B)], np.int32)
+
+    def step():
+        ex.extract_batch_dev(d_frames, B, W, H)
+        d_kp, d_desc, d_n, cap = ex.device_results()
+        fm.match_batch_dev(d_desc, cap, cap, d_n, pairs, L.MODE_BRUTEFORCE)
+        fm.sync()
+
+    for _ in range(args.warmup):
+        step()
+    ex.set_profiling(True); fm.set_profiling(True)
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        nfr = torch.tensor([B * args.steps], dtype=torch.int64, device=dev)
+        dist.all_reduce(nfr)                                        # units all ranks processed
+        total_frames = int(nfr.item())
+    else:
+        total_frames = B * args.steps
+
+    # per-kernel GPU time over the timed region
+    times = dict(ex.kernel_times()); times.update(fm.kernel_times())
+    ex.set_profiling(False); fm.set_profiling(False)
+    counts = ex.last_counts(B)
+    _, nmatch = fm.fetch_batch(counts_only=True)
+    px = level_pixels(ex, W, H)
+    pairs_rows = [(int(counts[a]), int(counts[b])) for a, b in pairs]
+    kern = {}
+    for name, (ms, launches) in times.items():
+        ab = algorithmic_bytes(name, B, px, int(counts.sum()), pairs_rows)
+        avg_us = ms * 1e3 / max(launches, 1)
+        kern[name] = {"total_ms": round(ms, 3), "launches": launches, "avg_us": round(avg_us, 2),
+                      "alg_bytes_per_launch": int(ab), "GBps": round(ab / (avg_us * 1e-6) / 1e9, 1) if avg_us > 0 else None}
+    dom = max(times, key=lambda k: times[k][0])
+    dom_avg_s = times[dom][0] * 1e-3 / times[dom][1]
+    dom_bytes = algorithmic_bytes(dom, B, px, int(counts.sum()), pairs_rows)
+    achieved = dom_bytes / dom_avg_s / 1e9
+    roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "avg_launch_us": round(dom_avg_s * 1e6, 2), "alg_bytes_per_launch": int(dom_bytes)}
+    # the matcher is VALU-bound (xor+popcount), not HBM-bound: report its VALU fraction beside it
+    if "k_hamming_knn2" in times:
+        ms, launches = times["k_hamming_knn2"]
+        pairs_eval = sum(nq * nt for nq, nt in pairs_rows)
+        rate = pairs_eval / (ms * 1e-3 / launches)
+        valu = {"kernel": "k_hamming_knn2", "descriptor_pairs_per_s": rate, "lane_ops_per_pair": 19,
+                "peak_lane_ops_per_s": VALU_PEAK_LANEOPS, "frac": round(19 * rate / VALU_PEAK_LANEOPS, 4)}
+    else:
+        valu = None
+
+    if rank == 0:
+        out = {
+            "metric": "ORB extract + BF-match frames/s @VGA (BASELINE config 2)",
+            "value": round(total_frames / dt, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: VGA %dx%d stream, %d features/frame, 8 levels, extract + MatchByBruteForce vs previous frame" % (W, H, args.features),
+                       "frames_per_step": B, "parallelism": "frames sharded over %d rank(s), replicas, no collective on the data path" % world,
+                       "host_threads": os.environ.get("SSVIO_HOST_THREADS", "auto")},
+            "keypoints_per_frame": round(float(counts.mean()), 1),
+            "matches_per_frame": round(float(nmatch.mean()), 1),
+            "query_matches_per_s": round(float(nmatch.sum()) * args.steps * world / dt, 1),
+            "roofline": roof, "valu": valu, "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, args.features)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    ex.close(); fm.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,7 @@ def lib():
         L.orc_distribute_octtree.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]
         L.orc_ic_angle.restype = f32; L.orc_ic_angle.argtypes = [vp, i32, i32, i32, vp, vp]
         L.orc_orb_descriptor.argtypes = [vp, i32, i32, i32, f32, vp]
+        L.orc_orb_descriptor_libm.argtypes = [vp, i32, i32, i32, f32, vp]
         L.orc_hamming256.restype = i32; L.orc_hamming256.argtypes = [vp, vp]
         L.orc_knn2_raw.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp, vp]
         L.orc_bf_nn.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp]
@@ -169,10 +170,11 @@ def ic_angle(img, x, y):
     return a, m01.value, m10.value
 
 
-def orb_descriptor(blurred, x, y, angle_deg):
+def orb_descriptor(blurred, x, y, angle_deg, libm=False):
     blurred = _u8(blurred)
     d = np.empty(32, np.uint8)
-    lib().orc_orb_descriptor(_p(blurred), blurred.strides[0], x, y, float(angle_deg), _p(d))
+    fn = lib().orc_orb_descriptor_libm if libm else lib().orc_orb_descriptor
+    fn(_p(blurred), blurred.strides[0], x, y, float(angle_deg), _p(d))
     return d
 
 

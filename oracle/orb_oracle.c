@@ -361,6 +361,30 @@ void orc_orb_descriptor(const uint8_t* img, int stride, int x, int y, float angl
     }
 }
 
+/* Same descriptor with the host libm's cosf/sinf -- what the reference binary would call
+ * (src/Feature.cpp:449) on THIS machine.  glibc's cosf/sinf are faithfully but not correctly
+ * rounded (and differ between its FMA and non-FMA ifunc variants), so they are no portable
+ * definition; this entry point exists so tests can count how many descriptors the choice of
+ * libm can change at all. */
+void orc_orb_descriptor_libm(const uint8_t* img, int stride, int x, int y, float angle_deg, uint8_t desc[32])
+{
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float angle = (float)angle_deg * factorPI;
+    float a = cosf(angle), b = sinf(angle);
+    const uint8_t* center = img + (size_t)y * stride + x;
+    const int8_t* p = k_pattern;
+    for (int i = 0; i < 32; ++i) {
+        int val = 0;
+        for (int k = 0; k < 8; ++k, p += 4) {
+            float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+            int t0 = center[orc_cvround(x0 * b + y0 * a) * stride + orc_cvround(x0 * a - y0 * b)];
+            int t1 = center[orc_cvround(x1 * b + y1 * a) * stride + orc_cvround(x1 * a - y1 * b)];
+            val |= (t0 < t1) << k;
+        }
+        desc[i] = (uint8_t)val;
+    }
+}
+
 /* ------------------------------------------------------------------ quadtree, src/Feature.cpp:17-81, 570-798 */
 typedef struct QNode {
     int ulx, uly, urx, ury, blx, bly, brx, bry;

@@ -70,6 +70,7 @@ int  orc_distribute_octtree(const float* xs, const float* ys, const float* resp,
 /* IC_Angle (:84-113) + rBRIEF (:446-482) at one keypoint */
 float orc_ic_angle(const uint8_t* img, int stride, int x, int y, int* m01, int* m10);
 void  orc_orb_descriptor(const uint8_t* blurred, int stride, int x, int y, float angle_deg, uint8_t desc[32]);
+void  orc_orb_descriptor_libm(const uint8_t* blurred, int stride, int x, int y, float angle_deg, uint8_t desc[32]); /* host libm cosf/sinf */
 
 /* ---- matching (src/FeatureMatching.cpp) ---- */
 int  orc_hamming256(const uint8_t* a, const uint8_t* b);                               /* :211-228 */

@@ -1,0 +1,35 @@
+"""The C++ adapter classes (include/ssvio/Feature.h, FeatureMatching.h) used the way SSVIO's
+Odometry/Frame use the reference classes; outputs compared with the oracle bit for bit."""
+import os
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "adapter_test")
+
+
+def test_adapters_compile_and_link_against_the_cabi():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_adapters_match_oracle(tmp_path):
+    from ssvio_amd import synth
+    from oracle import oracle as O
+    assert os.path.exists(EXE), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    a, b = synth.frame_pair(4, 240, 320)
+    raw = tmp_path / "frames.raw"
+    raw.write_bytes(a.tobytes() + b.tobytes())
+    out = str(tmp_path / "o")
+    r = subprocess.run([EXE, str(raw), "320", "240", "1200", out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "pyr0=320x240" in r.stdout
+    ex = O.Extractor(1200, 1.2, 8, 20, 7)
+    ka, da = ex.extract(a); kb, db = ex.extract(b)
+    rd = lambda suf: open(out + suf, "rb").read()
+    assert rd(".ka") == ka.tobytes() and rd(".kb") == kb.tobytes()
+    assert rd(".da") == da.tobytes() and rd(".db") == db.tobytes()
+    assert rd(".m") == O.match_bruteforce(db, da).tobytes()
+    assert rd(".m2") == O.match_knn2_ratio(db, da, 50, 0.6).tobytes()

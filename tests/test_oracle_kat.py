@@ -1,0 +1,277 @@
+"""CPU: the oracle against hand-derived known-answer vectors and against an independent
+numpy restatement of FAST.  The reference ships no tests or fixtures, so these KATs are the
+only pin the oracle has ("parity unpinned", see oracle/ssvio_oracle.h)."""
+import ctypes
+import ctypes.util
+import json
+import os
+import numpy as np
+import pytest
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def test_rounding_and_gray(oracle):
+    for v, r in KAT["cvround"]:
+        assert oracle.cvround(v) == r
+    for rgb, g in KAT["rgb2gray"]:
+        assert oracle.rgb2gray(np.array([[rgb]], np.uint8))[0, 0] == g
+
+
+def test_constructor_tables(oracle):
+    for nf, q in KAT["quotas"].items():
+        ex = oracle.Extractor(int(nf), 1.2, 8, 20, 7)
+        assert list(ex.features_per_level()) == q and sum(q) == int(nf)
+        assert list(ex.umax()) == KAT["umax"]
+    sf = oracle.Extractor(1000, 1.2, 8, 20, 7).scale_factors()
+    assert sf[0] == 1.0 and sf[1] == np.float32(1.2) and [int(15 * s) for s in sf] == KAT["kp_size"]
+    assert list(oracle.gauss_kernel_fixed()) == KAT["gauss_kernel_q8"]
+
+
+def test_level_sizes_and_cell_grid(oracle):
+    ex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    img = np.zeros((480, 640), np.uint8)
+    ex.extract(img)
+    for l, (w, h) in enumerate(KAT["levels_vga"]):
+        assert ex.level_size(l) == (w, h)
+        g = oracle.cell_grid(w, h)
+        assert [g["nCols"], g["nRows"], g["wCell"], g["hCell"]] == KAT["grid_vga"][l]
+    assert sum(w * h for w, h in KAT["levels_vga"]) == 950532 and sum(c * r for c, r, _, _ in KAT["grid_vga"]) == 815
+    tot = 0
+    for (w, h), (c, r) in zip(KAT["levels_1080p"], KAT["grid_1080p_colsrows"]):
+        g = oracle.cell_grid(w, h)
+        assert (g["nCols"], g["nRows"]) == (c, r)
+        tot += w * h
+    assert tot == 6419321
+    assert oracle.cell_grid(61, 100) is None        # narrower than one cell: the reference divides by zero
+
+
+def test_reflect101_border(oracle):
+    row = np.frombuffer(b"abcdefgh", np.uint8)
+    img = np.tile(row, (8, 1))
+    out = oracle.border_reflect101(img, 6)
+    assert bytes(out[6]) == b"gfedcbabcdefghgfedcb"      # gfedcb|abcdefgh|gfedcb  (edge pixel not repeated)
+    col = oracle.border_reflect101(img.T.copy(), 6)[:, 6]
+    assert bytes(col) == b"gfedcbabcdefghgfedcb"
+
+
+def test_resize_identity_constant_and_ramp(oracle):
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (40, 50), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear(a, 50, 40), a)                      # scale 1: weights (2048, 0)
+    assert (oracle.resize_linear(np.full((48, 60), 93, np.uint8), 50, 40) == 93).all()
+    # 2:1 horizontal shrink of a ramp: fx = 0.5 -> (S[2x]*1024 + S[2x+1]*1024), y weights (2048,0):
+    ramp = np.tile(np.arange(0, 64, dtype=np.uint8) * 2, (8, 1))
+    out = oracle.resize_linear(ramp, 32, 8)
+    exp = ((((2048 * ((ramp[:, 0::2].astype(np.int64) * 1024 + ramp[:, 1::2].astype(np.int64) * 1024) >> 4)) >> 16) + 2) >> 2)
+    assert np.array_equal(out, exp.astype(np.uint8))
+
+
+def test_blur_impulse_is_kernel_outer_product(oracle):
+    k = np.array(KAT["gauss_kernel_q8"], np.int64)
+    img = np.zeros((21, 21), np.uint8); img[10, 10] = 255
+    out = oracle.gaussian7(img)
+    exp = np.zeros((21, 21), np.int64)
+    exp[7:14, 7:14] = (np.outer(k, k) * 255 + 32768) >> 16
+    assert np.array_equal(out, exp.astype(np.uint8))
+    assert (oracle.gaussian7(np.full((30, 30), 255, np.uint8)) == 255).all()       # 255*257*257 saturates
+    assert (oracle.gaussian7(np.full((30, 30), 100, np.uint8)) == ((100 * 257 * 257 + 32768) >> 16)).all()
+
+
+def _patch(arc_len, start, bright=True, v=100, delta=50):
+    p = np.full((7, 7), v, np.uint8)
+    for i in range(arc_len):
+        dx, dy = RING[(start + i) % 16]
+        p[3 + dy, 3 + dx] = v + delta if bright else v - delta
+    return p
+
+
+def test_fast_arc_of_9_is_corner_arc_of_8_is_not(oracle):
+    for start in range(16):
+        for bright in (True, False):
+            xs, ys, sc = oracle.fast9(_patch(9, start, bright), 20)
+            assert list(xs) == [3] and list(ys) == [3] and list(sc) == [49], (start, bright)   # score = min|diff| - 1
+            xs, ys, sc = oracle.fast9(_patch(8, start, bright), 20)
+            assert len(xs) == 0
+    # threshold is strict: a 9-arc exactly at v+20 is not a corner at T=20 but is at T=19
+    assert len(oracle.fast9(_patch(9, 0, True, 100, 20), 20)[0]) == 0
+    assert list(oracle.fast9(_patch(9, 0, True, 100, 20), 19)[2]) == [19]
+
+
+def _fast_numpy(img, T):
+    """independent restatement of App. A3: corner <=> 9 contiguous ring pixels all darker than v-T or all
+    brighter than v+T; score = max(T, maxmin) - 1; strict NMS against the 8 neighbours' stored scores."""
+    h, w = img.shape
+    I = img.astype(np.int32)
+    sc = np.zeros((h, w), np.int32)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            d = np.array([I[y, x] - I[y + dy, x + dx] for dx, dy in RING])
+            dd = np.concatenate([d, d])
+            a = max(dd[k:k + 9].min() for k in range(16))
+            b = max((-dd[k:k + 9]).min() for k in range(16))
+            if a > T or b > T:
+                sc[y, x] = max(T, a, b) - 1
+    out = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = sc[y, x]
+            nb = sc[y - 1:y + 2, x - 1:x + 2].copy(); nb[1, 1] = -1
+            if s > 0 and (s > nb).all():
+                out.append((x, y, s))
+    return out
+
+
+@pytest.mark.parametrize("seed,T", [(1, 20), (2, 7), (3, 12), (4, 20)])
+def test_fast_oracle_equals_independent_numpy_definition(oracle, seed, T):
+    from ssvio_amd import synth
+    img = synth.texture(seed, 44, 52, n_shapes=40)
+    if seed == 4:                                   # plateau: equal adjacent scores must suppress each other
+        img = np.repeat(np.repeat(synth.texture(9, 22, 26, n_shapes=30), 2, 0), 2, 1)
+    xs, ys, sc = oracle.fast9(img, T)
+    ref = _fast_numpy(img, T)
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(xs, ys, sc)] == ref
+    assert len(ref) > 0
+
+
+def test_fast_score_is_threshold_independent_for_corners(oracle):
+    """the property the GPU kernel relies on: corner@T <=> score(T=0 definition) >= T"""
+    from ssvio_amd import synth
+    img = synth.texture(6, 60, 60, n_shapes=60)
+    for y in range(3, 57):
+        for x in range(3, 57):
+            s1 = oracle.fast_score_ref(img, x, y, 1)
+            for T in (7, 20, 35):
+                sT = oracle.fast_score_ref(img, x, y, T)
+                assert sT == max(s1, T - 1)
+
+
+def test_fast_atan2_axes_and_accuracy(oracle):
+    assert oracle.fast_atan2(0, 0) == 0.0
+    assert oracle.fast_atan2(0, 5) == 0.0 and oracle.fast_atan2(0, -5) == 180.0
+    assert abs(oracle.fast_atan2(5, 0) - 90.0) < 1e-4 and abs(oracle.fast_atan2(-5, 0) - 270.0) < 1e-4
+    rng = np.random.default_rng(1)
+    for y, x in rng.normal(size=(500, 2)) * 1000:
+        ref = np.degrees(np.arctan2(y, x)) % 360
+        assert abs(oracle.fast_atan2(y, x) - ref) < 0.02 or abs(oracle.fast_atan2(y, x) - ref) > 359.98
+
+
+def test_sincos_is_correctly_rounded_and_within_1ulp_of_libm(oracle):
+    """canonical cosf/sinf = double evaluation rounded once (== correctly rounded on the sample).  glibc's
+    cosf/sinf are only faithfully rounded: they differ from it by 1 ulp on a few % of inputs (and between
+    glibc's FMA / non-FMA variants), which is why libm is not the definition."""
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([rng.uniform(0, 6.2831855, 200000), np.arange(0, 360, 0.25) * np.pi / 180]).astype(np.float32)
+    s = np.empty(len(xs), np.float32); c = np.empty(len(xs), np.float32)
+    L = oracle.lib()
+    sv = ctypes.c_float(); cv = ctypes.c_float()
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.cosf.restype = ctypes.c_float; libm.cosf.argtypes = [ctypes.c_float]
+    libm.sinf.restype = ctypes.c_float; libm.sinf.argtypes = [ctypes.c_float]
+    bad_libm = 0
+    for i, x in enumerate(xs):
+        L.orc_sincosf(float(x), ctypes.byref(sv), ctypes.byref(cv))
+        s[i] = sv.value; c[i] = cv.value
+        if i < 40000:
+            lc, ls = libm.cosf(float(x)), libm.sinf(float(x))
+            if lc != cv.value or ls != sv.value:
+                bad_libm += 1
+                assert abs(lc - cv.value) <= np.spacing(np.float32(max(abs(lc), 1e-3))) and abs(ls - sv.value) <= np.spacing(np.float32(max(abs(ls), 1e-3)))
+    assert np.array_equal(c, np.cos(xs.astype(np.float64)).astype(np.float32))
+    assert np.array_equal(s, np.sin(xs.astype(np.float64)).astype(np.float32))
+    assert bad_libm < 0.06 * 40000
+
+
+def test_descriptors_do_not_depend_on_the_libm_choice_on_real_frames(oracle):
+    """north-star: 'keypoints whose angle bin flips at a boundary are reported separately' -- count the
+    descriptors that change when the rotation uses the host libm instead of the canonical sincos"""
+    from ssvio_amd import synth
+    ex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    img = synth.texture(12, 480, 640)
+    kps, desc = ex.extract(img)
+    flips = 0; k = 0
+    for l in range(8):
+        b = ex.level_blur(l)
+        for kp in ex.level_keypoints(l):
+            d = oracle.orb_descriptor(b, int(kp["x"]), int(kp["y"]), float(kp["angle"]), libm=True)
+            flips += int(not np.array_equal(d, desc[k])); k += 1
+    assert k == len(kps)
+    assert flips <= 2, "descriptors changed by the libm choice: %d of %d" % (flips, k)
+
+
+def test_ic_angle_moments_follow_the_variant_as_written(oracle):
+    """v = 1..14 only and u = -d..d-1 (src/Feature.cpp:98,102), not ORB-SLAM2's symmetric patch"""
+    from ssvio_amd import synth
+    img = synth.texture(8, 64, 64, n_shapes=50)
+    umax = KAT["umax"]
+    I = img.astype(np.int64)
+    for (x, y) in [(20, 20), (31, 33), (40, 25)]:
+        m10 = sum(u * I[y, x + u] for u in range(-15, 16)); m01 = 0
+        for v in range(1, 15):
+            d = umax[v]
+            for u in range(-d, d):
+                m10 += u * (I[y + v, x + u] + I[y - v, x + u]); m01 += v * (I[y + v, x + u] - I[y - v, x + u])
+        a, r01, r10 = oracle.ic_angle(img, x, y)
+        assert (r01, r10) == (m01, m10)
+        assert a == oracle.fast_atan2(float(np.float32(m01)), float(np.float32(m10)))
+
+
+def test_descriptor_constant_patch_and_known_bits(oracle):
+    assert (oracle.orb_descriptor(np.full((64, 64), 9, np.uint8), 32, 32, 123.4) == 0).all()
+    # angle 0: a = 1, b = 0 -> sample (x, y) = pattern itself; first pair (8,-3) vs (9,5)
+    img = np.zeros((64, 64), np.uint8); img[32 + 5, 32 + 9] = 200
+    d = oracle.orb_descriptor(img, 32, 32, 0.0)
+    assert d[0] & 1 == 1
+    img2 = np.zeros((64, 64), np.uint8); img2[32 - 3, 32 + 8] = 200
+    assert oracle.orb_descriptor(img2, 32, 32, 0.0)[0] & 1 == 0
+    # angle 90: a = 0 (exactly? cosf(pi/2 as float) = -4.37e-8), b = 1: sample row = x*b + y*a, col = x*a - y*b
+    d90 = oracle.orb_descriptor(np.fromfunction(lambda y, x: (x * 3 + y * 5) % 251, (64, 64)).astype(np.uint8), 32, 32, 90.0)
+    assert d90.shape == (32,)
+
+
+def test_hamming_and_bf_semantics(oracle):
+    z = np.zeros(32, np.uint8); o = np.full(32, 255, np.uint8)
+    assert oracle.hamming256(z, z) == 0 and oracle.hamming256(z, o) == 256
+    one = z.copy(); one[17] = 0x10
+    assert oracle.hamming256(z, one) == 1
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (50, 32), dtype=np.uint8); b = rng.integers(0, 256, (60, 32), dtype=np.uint8)
+    D = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+    idx, d = oracle.bf_nn(a, b)
+    assert np.array_equal(idx, D.argmin(1)) and np.array_equal(d, D.min(1))          # argmin = lowest index on ties
+    b2 = np.concatenate([b, b])
+    idx2, _ = oracle.bf_nn(a, b2)
+    assert np.array_equal(idx2, idx)
+    i3, d1, d2 = oracle.knn2_raw(a, b2)
+    assert np.array_equal(d1, d2)                                                      # duplicate train rows: second best == best
+    srt = np.sort(D, axis=1)
+    i4, e1, e2 = oracle.knn2_raw(a, b)
+    assert np.array_equal(e1, srt[:, 0]) and np.array_equal(e2, srt[:, 1])
+    # filter boundary: dist < max(2*min, 30)
+    t = np.zeros((1, 32), np.uint8); q = np.zeros((4, 32), np.uint8)
+    for r, n in enumerate((10, 29, 30, 31)):
+        bits = np.zeros(256, np.uint8); bits[:n] = 1; q[r] = np.packbits(bits, bitorder="little")
+    m = oracle.match_bruteforce(q, t)
+    assert list(m["queryIdx"]) == [0, 1] and list(m["distance"]) == [10.0, 29.0] and (m["imgIdx"] == 0).all()
+    assert len(oracle.match_bruteforce(np.zeros((0, 32), np.uint8), t)) == 0
+    m2 = oracle.match_knn2_ratio(a, b, 256, 2.0)
+    assert len(m2) == 50 and (m2["imgIdx"] == -1).all()
+
+
+def test_quadtree_small_cases(oracle):
+    # one key per quadrant of a square region, N = 4: one split, list order = reverse creation (n4,n3,n2,n1)
+    xs = np.array([10, 90, 10, 90], np.float32); ys = np.array([10, 10, 90, 90], np.float32); r = np.array([1, 2, 3, 4], np.float32)
+    sel, tie = oracle.distribute_octtree(xs, ys, r, 0, 100, 0, 100, 4)
+    assert list(sel) == [3, 2, 1, 0]
+    # N = 1: the root is still divided once (the loop runs before the size test)
+    sel, _ = oracle.distribute_octtree(xs, ys, r, 0, 100, 0, 100, 1)
+    assert list(sel) == [3, 2, 1, 0]
+    # two keys in one cell, best response wins, first wins on equal response
+    xs = np.array([10, 11, 12], np.float32); ys = np.array([10, 10, 10], np.float32)
+    sel, _ = oracle.distribute_octtree(xs, ys, np.array([5, 9, 9], np.float32), 0, 100, 0, 100, 1)
+    assert list(sel) == [1]
+    # wide region: two roots (nIni = round(200/100))
+    xs = np.array([10, 150], np.float32); ys = np.array([10, 10], np.float32)
+    sel, _ = oracle.distribute_octtree(xs, ys, np.array([1, 1], np.float32), 0, 200, 0, 100, 5)
+    assert list(sel) == [0, 1]
