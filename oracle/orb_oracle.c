@@ -49,6 +49,16 @@ void orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride,
 {
     double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
     double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    if (scale_x == 2.0 && scale_y == 2.0) {
+        /* OpenCV 3.x: INTER_LINEAR with an exact 2:1 shrink in both directions silently becomes
+         * INTER_AREA, whose 8U 2x2 fast path is (a+b+c+d+2)>>2 (SURVEY App. A2 note) */
+        for (int dy = 0; dy < dh; ++dy) {
+            const uint8_t* S0 = src + (size_t)(2 * dy) * sstride; const uint8_t* S1 = S0 + sstride;
+            for (int dx = 0; dx < dw; ++dx)
+                dst[(size_t)dy * dstride + dx] = (uint8_t)((S0[2 * dx] + S0[2 * dx + 1] + S1[2 * dx] + S1[2 * dx + 1] + 2) >> 2);
+        }
+        return;
+    }
     int* xofs = (int*)malloc(sizeof(int) * dw);
     short* ialpha = (short*)malloc(sizeof(short) * 2 * dw);
     int* T0 = (int*)malloc(sizeof(int) * dw);

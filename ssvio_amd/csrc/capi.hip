@@ -148,7 +148,7 @@ struct ssvio_orb {
     int candCap = 0;               // candidates per frame (all levels)
     size_t inBytes = 0;
     uint8_t* d_in = nullptr; uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr;
-    int16_t* d_tabs = nullptr; std::vector<size_t> xTabOff, yTabOff;
+    int16_t* d_tabs = nullptr; std::vector<size_t> xTabOff, yTabOff, qTabOff; std::vector<char> quadOk; std::vector<int> resizeRows;
     uint32_t* d_slots = nullptr; int* d_cellCount = nullptr;
     uint32_t* d_cand = nullptr; int* d_candCount = nullptr;
     uint2* d_kpIn = nullptr; int* d_kpCount = nullptr;
@@ -177,11 +177,11 @@ static void fill_klevels(const PyramidGeom& g, KLevels& k)
         k.w[l] = L.w; k.h[l] = L.h; k.pitch[l] = L.pitch; k.offset[l] = L.offset;
         k.nCols[l] = L.nCols; k.nRows[l] = L.nRows; k.wCell[l] = L.wCell; k.hCell[l] = L.hCell;
         k.cellBase[l] = L.cellBase; k.slotCap[l] = L.slotCap; k.slotBase[l] = L.slotBase;
-        k.blurTileBase[l] = L.blurTileBase; k.blurTilesX[l] = L.blurTilesX;
+        k.blurStripBase[l] = L.blurStripBase; k.blurStripsX[l] = L.blurStripsX; k.blurIters[l] = L.blurIters;
         k.scale[l] = L.scale; k.kpSize[l] = L.kpSize;
     }
     k.cellBase[g.nlevels] = g.cellsPerFrame;
-    k.blurTileBase[g.nlevels] = g.blurTilesPerFrame;
+    k.blurStripBase[g.nlevels] = g.blurStripsPerFrame;
 }
 
 // (re)allocate for a w x h x batch configuration
@@ -199,12 +199,14 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
         fill_klevels(g, h->kl);
         // resize tables
         std::vector<int16_t> all;
-        h->xTabOff.assign(g.nlevels, 0); h->yTabOff.assign(g.nlevels, 0);
+        h->xTabOff.assign(g.nlevels, 0); h->yTabOff.assign(g.nlevels, 0); h->qTabOff.assign(g.nlevels, 0); h->quadOk.assign(g.nlevels, 0); h->resizeRows.assign(g.nlevels, 1);
         for (int l = 1; l < g.nlevels; ++l) {
             ResizeTabs t;
             build_resize_tabs(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h, t);
             h->xTabOff[l] = all.size(); all.insert(all.end(), t.xs.begin(), t.xs.end());
             h->yTabOff[l] = all.size(); all.insert(all.end(), t.ys.begin(), t.ys.end());
+            while (all.size() % 16) all.push_back(0);
+            h->qTabOff[l] = all.size(); all.insert(all.end(), t.quads.begin(), t.quads.end()); h->quadOk[l] = t.area2 ? 2 : (t.quadOk ? 1 : 0); h->resizeRows[l] = t.rows;
         }
         if (all.empty()) all.resize(4);
         SSVIO_HIP(hipMalloc(&h->d_tabs, all.size() * sizeof(int16_t)));
@@ -264,7 +266,7 @@ static int orb_run(ssvio_orb* h, int batch)
     hipStream_t s = h->stream;
     for (int l = 1; l < g.nlevels; ++l) {
         ProfScope p(h->prof, "k_resize", s);
-        launch_resize(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], batch, s);
+        launch_resize(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], h->qTabOff[l], (int)h->quadOk[l], h->resizeRows[l], batch, s);
     }
     {
         ProfScope p(h->prof, "k_fast_cells", s);
@@ -282,7 +284,7 @@ static int orb_run(ssvio_orb* h, int batch)
         if (attempt == 0) {
             // the blur does not depend on the keypoints: it runs while the host distributes them
             ProfScope p(h->prof, "k_blur", s);
-            launch_blur(h->d_pyr, h->d_blur, g.frameBytes, h->kl, g.blurTilesPerFrame, batch, s);
+            launch_blur(h->d_pyr, h->d_blur, g.frameBytes, h->kl, g.blurStripsPerFrame, batch, s);
         }
         SSVIO_HIP(hipEventSynchronize(h->evCand));
         int need = 0;
@@ -434,8 +436,8 @@ int ssvio_orb_extract_batch_dev(ssvio_orb* h, const void* d_imgs, int batch, int
     const PyramidGeom& g = h->geom;
     {
         ProfScope p(h->prof, channels == 3 ? "k_rgb2gray" : "k_copy_gray", h->stream);
-        if (channels == 3) launch_rgb2gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr, g.frameBytes, g.lv[0].pitch, h->stream);
-        else launch_copy_gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr, g.frameBytes, g.lv[0].pitch, h->stream);
+        if (channels == 3) launch_rgb2gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch, h->stream);
+        else launch_copy_gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch, h->stream);
     }
     rc = orb_run(h, batch);
     if (rc) return rc;
@@ -493,19 +495,16 @@ int ssvio_orb_extract_batch(ssvio_orb* h, const uint8_t* imgs, int batch, int ch
     if (!imgs || width <= 0 || height <= 0 || batch == 0) { for (int f = 0; f < batch; ++f) n[f] = 0; h->lastBatch = 0; h->haveResults = false; return SSVIO_OK; }
     if (stride < width * channels) { set_error("stride %d < row bytes %d", stride, width * channels); return SSVIO_ERR_INVALID; }
     const size_t rowBytes = (size_t)width * channels;
-    int rc = orb_ensure(h, width, height, batch, channels == 3 ? (size_t)batch * rowBytes * height : 0);
+    int rc = orb_ensure(h, width, height, batch, (size_t)batch * rowBytes * height);
     if (rc) return rc;
     const PyramidGeom& g = h->geom;
-    if (channels == 1) {
-        for (int f = 0; f < batch; ++f)
-            SSVIO_HIP(hipMemcpy2DAsync(h->d_pyr + (size_t)f * g.frameBytes, g.lv[0].pitch, imgs + (size_t)f * frame_stride, stride,
-                                       rowBytes, height, hipMemcpyHostToDevice, h->stream));
-    } else {
-        for (int f = 0; f < batch; ++f)
-            SSVIO_HIP(hipMemcpy2DAsync(h->d_in + (size_t)f * rowBytes * height, rowBytes, imgs + (size_t)f * frame_stride, stride,
-                                       rowBytes, height, hipMemcpyHostToDevice, h->stream));
-        ProfScope p(h->prof, "k_rgb2gray", h->stream);
-        launch_rgb2gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr, g.frameBytes, g.lv[0].pitch, h->stream);
+    for (int f = 0; f < batch; ++f)
+        SSVIO_HIP(hipMemcpy2DAsync(h->d_in + (size_t)f * rowBytes * height, rowBytes, imgs + (size_t)f * frame_stride, stride,
+                                   rowBytes, height, hipMemcpyHostToDevice, h->stream));
+    {
+        ProfScope p(h->prof, channels == 3 ? "k_rgb2gray" : "k_copy_gray", h->stream);
+        if (channels == 3) launch_rgb2gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch, h->stream);
+        else launch_copy_gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch, h->stream);
     }
     rc = orb_run(h, batch);
     if (rc) return rc;

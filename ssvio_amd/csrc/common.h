@@ -14,6 +14,7 @@ constexpr int kMaxLevels = SSVIO_MAX_LEVELS;
 constexpr int kEdge = 19;          // EDGE_THRESHOLD, src/Feature.cpp:14
 constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE, src/Feature.cpp:13
 constexpr int kMinBorder = 16;     // EDGE_THRESHOLD - 3, src/Feature.cpp:835
+constexpr int kPadX = 4;          // reflect-101 columns kept on both sides of every level row (for k_blur)
 constexpr int kMaxCellDim = 64;    // interior of a FAST cell window never exceeds 59 px (see geometry.cpp)
 
 void set_error(const char* fmt, ...);
@@ -38,7 +39,7 @@ struct LevelGeom {
     int quota;                // mnFeaturesPerLevel
     float scale;              // mvScaleFactor
     int kpSize;               // (int)(15*scale)
-    int blurTileBase, blurTilesX, blurTilesY;
+    int blurStripBase, blurStripsX, blurStripsY, blurIters;   // k_blur strips: 120 px wide, 7*blurIters-6 rows tall
     size_t tabOffset;         // offset (in shorts) of this level's resize tables
 };
 
@@ -49,7 +50,7 @@ struct PyramidGeom {
     size_t frameBytes = 0;    // pyramid bytes per frame
     int cellsPerFrame = 0;
     size_t slotsPerFrame = 0;
-    int blurTilesPerFrame = 0;
+    int blurStripsPerFrame = 0;
     int maxQuotaSum = 0;
 };
 
@@ -62,7 +63,7 @@ struct KLevels {
     int cellBase[kMaxLevels + 1];
     int slotCap[kMaxLevels];
     unsigned long long slotBase[kMaxLevels];
-    int blurTileBase[kMaxLevels + 1], blurTilesX[kMaxLevels];
+    int blurStripBase[kMaxLevels + 1], blurStripsX[kMaxLevels], blurIters[kMaxLevels];
     float scale[kMaxLevels];
     int kpSize[kMaxLevels];
 };
@@ -77,8 +78,11 @@ int  build_tables(const ssvio_orb_params& p, ExtractorTables& t);
 // returns SSVIO_OK or SSVIO_ERR_GEOMETRY
 int  build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom& g);
 // resize coefficient tables for level l (from level l-1): per dst x: {sx, a0, a1}, per dst y: {sy0, sy1, b0, b1}
-struct ResizeTabs { std::vector<int16_t> xs, ys; };   // xs: 4 shorts per dx (sx, a0, a1, 0); ys: 4 per dy
+struct ResizeTabs { std::vector<int16_t> xs, ys, quads; bool quadOk; bool area2; int rows; };   // rows: output rows per wave of k_resize_quad   // area2: exact 2:1 shrink -> INTER_AREA   // xs: 4 shorts per dx; ys: 4 per dy; quads: 16 shorts per 4 dx
 void build_resize_tabs(int sw, int sh, int dw, int dh, ResizeTabs& t);
+// per output quad (4 adjacent dx) entry of the streaming resize kernel, 32 bytes
+struct ResizeQuad { uint32_t bOff; uint32_t sel0, sel1; int16_t a0[4], a1[4]; uint32_t pad; };
+static_assert(sizeof(ResizeQuad) == 32, "ResizeQuad is 16 shorts");
 
 // host quadtree (src/Feature.cpp:570-798)
 int  distribute_octtree(const float* xs, const float* ys, const float* resp, int n,
@@ -113,12 +117,12 @@ void launch_rgb2gray(const uint8_t* src, int w, int h, int stride, size_t frameS
 void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
                       uint8_t* pyr, size_t pyrFrameBytes, int pitch0, hipStream_t s);
 void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int level, const int16_t* tabs,
-                   size_t xTabOff, size_t yTabOff, int batch, hipStream_t s);
+                   size_t xTabOff, size_t yTabOff, size_t quadTabOff, int mode /*0 generic, 1 quad, 2 area 2x2*/, int rows, int batch, hipStream_t s);
 void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int cellsPerFrame, size_t slotsPerFrame,
                  int iniTh, int minTh, uint32_t* slots, int* cellCount, int batch, hipStream_t s);
 void launch_compact(const KLevels& kl, int cellsPerFrame, size_t slotsPerFrame, const uint32_t* slots, const int* cellCount,
                     uint32_t* cand, int candCap, int* candCount /*[batch][kMaxLevels+1]*/, int batch, hipStream_t s);
-void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, int batch, hipStream_t s);
+void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int stripsPerFrame, int batch, hipStream_t s);
 // kpIn: per keypoint {x | y<<16, level | resp<<8}; offsets per frame = f*cap
 void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl,
                      const uint2* kpIn, const int* kpCount, int cap, ssvio_keypoint* kpOut, uint8_t* desc, int batch, hipStream_t s);

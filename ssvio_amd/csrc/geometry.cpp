@@ -78,20 +78,26 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
         const int nIni = (int)std::round(fw / fh);                    // src/Feature.cpp:574
         if (nIni < 1) { set_error("level %d aspect ratio %g rounds to zero quadtree roots (src/Feature.cpp:574)", l, fw / fh); return SSVIO_ERR_GEOMETRY; }
         if (L.wCell > kMaxCellDim || L.hCell > kMaxCellDim) { set_error("internal: cell %dx%d exceeds %d", L.wCell, L.hCell, kMaxCellDim); return SSVIO_ERR_GEOMETRY; }
-        L.pitch = ((L.w + 63) / 64) * 64 + 64;          // 64-B aligned rows with >= 64 B of slack for vector reads
-        L.offset = off;
+        L.pitch = ((L.w + 63) / 64) * 64 + 128;         // 64-B aligned rows, 64 B of slack on both sides (pad columns, vector reads)
+        L.offset = off + 64;                            // x = 0 of row 0
         off += (size_t)L.pitch * (L.h + 1);
         off = (off + 255) & ~(size_t)255;
         L.cellBase = cell; cell += L.nCols * L.nRows;
         L.slotCap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);        // NMS leaves no two 8-adjacent maxima
         L.slotBase = slot; slot += (size_t)L.slotCap * L.nCols * L.nRows;
         L.quota = t.quota[l]; L.scale = t.scale[l]; L.kpSize = (int)(kHalfPatch * t.scale[l]);   // src/Feature.cpp:900
-        L.blurTilesX = (L.w + 63) / 64; L.blurTilesY = (L.h + 15) / 16;
-        L.blurTileBase = tiles; tiles += L.blurTilesX * L.blurTilesY;
+        // k_blur strips: 120 output px wide (32 lanes x 4 px, first/last lane are halo), 7*iters-6 rows tall
+        L.blurStripsX = (L.w + 119) / 120;
+        {
+            const int nsY = (L.h + 56) / 57, rows = (L.h + nsY - 1) / nsY;
+            L.blurIters = (rows + 6 + 6) / 7;
+            L.blurStripsY = (L.h + (7 * L.blurIters - 6) - 1) / (7 * L.blurIters - 6);
+        }
+        L.blurStripBase = tiles; tiles += L.blurStripsX * L.blurStripsY;
         g.maxQuotaSum += L.quota;
     }
     g.frameBytes = off + 256;
-    g.cellsPerFrame = cell; g.slotsPerFrame = slot; g.blurTilesPerFrame = tiles;
+    g.cellsPerFrame = cell; g.slotsPerFrame = slot; g.blurStripsPerFrame = tiles;
     return SSVIO_OK;
 }
 
@@ -102,6 +108,7 @@ void build_resize_tabs(int sw, int sh, int dw, int dh, ResizeTabs& t)
 {
     const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
     t.xs.assign((size_t)dw * 4, 0); t.ys.assign((size_t)dh * 4, 0);
+    t.area2 = scale_x == 2.0 && scale_y == 2.0;     // cv::resize turns INTER_LINEAR into INTER_AREA here
     for (int dx = 0; dx < dw; ++dx) {
         float fx = (float)((dx + 0.5) * scale_x - 0.5);
         int sx = (int)std::floor(fx);
@@ -121,6 +128,40 @@ void build_resize_tabs(int sw, int sh, int dw, int dh, ResizeTabs& t)
         t.ys[dy * 4 + 1] = (int16_t)std::min(std::max(sy + 1, 0), sh - 1);
         t.ys[dy * 4 + 2] = sat_short((1.f - fy) * 2048);
         t.ys[dy * 4 + 3] = sat_short(fy * 2048);
+    }
+    // quad table for k_resize_quad: the 8 source taps of 4 adjacent outputs lie in a window of <= 8 bytes
+    // starting at sx(dx0) when the scale is <= ~2; then two v_perm selectors per row replace 8 byte loads
+    const int nq = (dw + 2 * kPadX + 3) / 4;            // quad q covers dst x = 4q-4 .. 4q-1 (pad columns included)
+    t.quads.assign((size_t)nq * 16, 0);
+    t.quadOk = true;
+    for (int q = 0; q < nq; ++q) {
+        ResizeQuad e; memset(&e, 0, sizeof e);
+        int dxs[4], s0 = 1 << 30;
+        for (int i = 0; i < 4; ++i) {
+            int p = 4 * q - kPadX + i;
+            p = p < 0 ? -p : p; p = p >= dw ? 2 * dw - 2 - p : p;          // reflect-101 pad columns
+            dxs[i] = std::min(std::max(p, 0), dw - 1);
+            s0 = std::min(s0, (int)t.xs[dxs[i] * 4 + 0]);
+        }
+        e.bOff = (uint32_t)(s0 >> 2) | ((uint32_t)(s0 & 3) << 24);
+        for (int i = 0; i < 4; ++i) {
+            const int dx = dxs[i];
+            const int p0 = t.xs[dx * 4 + 0] - s0, p1 = t.xs[dx * 4 + 1] - s0;
+            if (p0 < 0 || p0 > 7 || p1 < 0 || p1 > 7) t.quadOk = false;
+            e.sel0 |= (uint32_t)(p0 & 7) << (8 * i); e.sel1 |= (uint32_t)(p1 & 7) << (8 * i);
+            e.a0[i] = t.xs[dx * 4 + 2]; e.a1[i] = t.xs[dx * 4 + 3];
+        }
+        memcpy(&t.quads[(size_t)q * 16], &e, sizeof e);
+    }
+    // output rows per wave: the strip's source rows must fit the kernel's 12-row register window
+    t.rows = std::min(8, std::max(1, (int)(10.0 / scale_y)));
+    for (bool ok = false; !ok && t.rows >= 1;) {
+        ok = true;
+        for (int y = 0; y < dh && ok; y += t.rows) {
+            const int ye = std::min(y + t.rows, dh) - 1;
+            if (t.ys[ye * 4 + 1] - t.ys[y * 4 + 0] + 1 > 12) ok = false;
+        }
+        if (!ok && --t.rows < 1) { t.rows = 1; t.quadOk = false; break; }
     }
 }
 

@@ -18,93 +18,179 @@
 namespace ssvio {
 
 // ---------------------------------------------------------------------------
-// level 0: copy / RGB2GRAY (src/Frame.cpp:7; SURVEY App. A1: 14-bit fixed point)
-__global__ __launch_bounds__(256) void k_copy_gray(const uint8_t* __restrict__ src, int w, int h, int stride, size_t frameStride,
-                                                   uint8_t* __restrict__ pyr, size_t pyrFrameBytes, int pitch0)
-{
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const uint8_t* s = src + (size_t)blockIdx.z * frameStride + (size_t)y * stride + x;
-    uint8_t* d = pyr + (size_t)blockIdx.z * pyrFrameBytes + (size_t)y * pitch0 + x;
-    uint32_t v = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) if (x + i < w) v |= (uint32_t)s[i] << (8 * i);
-    *(uint32_t*)d = v;           // rows have >= 64 B slack, 4-B aligned
-}
+// Every level row carries kPadX reflect-101 columns on both sides (x = -4..-1 and w..w+3), written
+// by the kernel that produces the level, so that the streaming blur can load plain aligned dwords
+// at the image edges.  (This is a 4-px slice of the reference's 19-px rim, used only internally.)
+__device__ __forceinline__ int refl101(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * n - 2 - p : p; }
+__device__ __forceinline__ int refl_clamp(int p, int n) { return min(max(refl101(p, n), 0), n - 1); }
 
-__global__ __launch_bounds__(256) void k_rgb2gray(const uint8_t* __restrict__ src, int w, int h, int stride, size_t frameStride,
-                                                  uint8_t* __restrict__ pyr, size_t pyrFrameBytes, int pitch0)
+// level 0: copy / RGB2GRAY (src/Frame.cpp:7; SURVEY App. A1: 14-bit fixed point).  Thread = output quad
+// x0 = 4*qi - 4 .. x0+3 of one row.
+template <int CH>
+__global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int w, int h, int stride, size_t frameStride,
+                                                uint8_t* __restrict__ pyr, size_t pyrFrameBytes, int pitch0, int aligned4)
 {
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - kPadX;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const uint8_t* s = src + (size_t)blockIdx.z * frameStride + (size_t)y * stride + (size_t)x * 3;
-    uint8_t* d = pyr + (size_t)blockIdx.z * pyrFrameBytes + (size_t)y * pitch0 + x;
+    if (x0 >= w + kPadX || y >= h) return;
+    const uint8_t* s = src + (size_t)blockIdx.z * frameStride + (size_t)y * stride;
+    uint8_t* d = pyr + (size_t)blockIdx.z * pyrFrameBytes + (size_t)y * pitch0 + x0;
     uint32_t v = 0;
+    if (CH == 1 && aligned4 && x0 >= 0 && x0 + 3 < w) v = *(const uint32_t*)(s + x0);
+    else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (x + i < w) {
-            const uint32_t g = (s[3 * i] * 4899u + s[3 * i + 1] * 9617u + s[3 * i + 2] * 1868u + 8192u) >> 14;
+        for (int i = 0; i < 4; ++i) {
+            const int c = refl_clamp(x0 + i, w);
+            uint32_t g;
+            if (CH == 1) g = s[c];
+            else g = (s[3 * c] * 4899u + s[3 * c + 1] * 9617u + s[3 * c + 2] * 1868u + 8192u) >> 14;
             v |= g << (8 * i);
         }
-    *(uint32_t*)d = v;
+    }
+    *(uint32_t*)d = v;           // rows are 4-B aligned with >= 64 B of slack on both sides
 }
 
 void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
                       uint8_t* pyr, size_t pyrFrameBytes, int pitch0, hipStream_t s)
 {
-    dim3 grid((w + 255) / 256, (h + 3) / 4, batch);
-    hipLaunchKernelGGL(k_copy_gray, grid, dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0);
+    dim3 grid((w + 2 * kPadX + 255) / 256, (h + 3) / 4, batch);
+    const int aligned4 = ((uintptr_t)src % 4 == 0) && (stride % 4 == 0) && (frameStride % 4 == 0);
+    hipLaunchKernelGGL(k_level0<1>, grid, dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, aligned4);
 }
 void launch_rgb2gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
                      uint8_t* pyr, size_t pyrFrameBytes, int pitch0, hipStream_t s)
 {
-    dim3 grid((w + 255) / 256, (h + 3) / 4, batch);
-    hipLaunchKernelGGL(k_rgb2gray, grid, dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0);
+    dim3 grid((w + 2 * kPadX + 255) / 256, (h + 3) / 4, batch);
+    hipLaunchKernelGGL(k_level0<3>, grid, dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, 0);
 }
 
 // ---------------------------------------------------------------------------
-// pyramid level l from level l-1: cv::resize INTER_LINEAR 8UC1 (src/Feature.cpp:813, App. A2).
-// Block = 64x4 threads, each thread 4 horizontally adjacent outputs -> a 256x4 output tile.
-// The two source rows of an output row are shared by the whole wave; coefficients come
-// from host-built tables (xs: {sx0, sx1, a0, a1} per dx; ys: {sy0, sy1, b0, b1} per dy).
+// pyramid level l from level l-1: cv::resize INTER_LINEAR 8UC1 (src/Feature.cpp:813, App. A2);
+// coefficients come from host-built tables (xs: {sx0, sx1, a0, a1} per dx; ys: {sy0, sy1, b0, b1}
+// per dy).  Generic form (any scale; also the exact-2:1 INTER_AREA case): one thread per output quad.
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_t pyrFrameBytes,
                                                 unsigned long long srcOff, int srcPitch,
                                                 unsigned long long dstOff, int dstPitch, int dw, int dh,
-                                                const short4* __restrict__ xtab, const short4* __restrict__ ytab)
+                                                const short4* __restrict__ xtab, const short4* __restrict__ ytab, int area2)
 {
-    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - kPadX;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dw || y >= dh) return;
+    if (x0 >= dw + kPadX || y >= dh) return;
     const uint8_t* S = pyr + (size_t)blockIdx.z * pyrFrameBytes + srcOff;
-    uint8_t* D = pyr + (size_t)blockIdx.z * pyrFrameBytes + dstOff + (size_t)y * dstPitch + x;
+    uint8_t* D = pyr + (size_t)blockIdx.z * pyrFrameBytes + dstOff + (size_t)y * dstPitch + x0;
+    uint32_t v = 0;
+    if (area2) {       // exact 2:1 shrink: cv::resize uses INTER_AREA, (a+b+c+d+2)>>2
+        const uint8_t* A = S + (size_t)(2 * y) * srcPitch; const uint8_t* B = A + srcPitch;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = refl_clamp(x0 + i, dw);
+            v |= (uint32_t)((A[2 * x] + A[2 * x + 1] + B[2 * x] + B[2 * x + 1] + 2) >> 2) << (8 * i);
+        }
+        *(uint32_t*)D = v;
+        return;
+    }
     const short4 ty = ytab[y];
     const uint8_t* S0 = S + (size_t)ty.x * srcPitch;
     const uint8_t* S1 = S + (size_t)ty.y * srcPitch;
     const int b0 = ty.z, b1 = ty.w;
-    uint32_t v = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (x + i < dw) {
-            const short4 tx = xtab[x + i];
-            const int t0 = S0[tx.x] * tx.z + S0[tx.y] * tx.w;
-            const int t1 = S1[tx.x] * tx.z + S1[tx.y] * tx.w;
-            const int r = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-            v |= (uint32_t)(r & 255) << (8 * i);
-        }
+        const short4 tx = xtab[refl_clamp(x0 + i, dw)];
+        const int t0 = S0[tx.x] * tx.z + S0[tx.y] * tx.w;
+        const int t1 = S1[tx.x] * tx.z + S1[tx.y] * tx.w;
+        const int r = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+        v |= (uint32_t)(r & 255) << (8 * i);
     }
     *(uint32_t*)D = v;
 }
 
+// Streaming form, used whenever the 8 taps of an output quad fit an 8-byte source window (scale <= ~2).
+// A wave owns 64 output quads (256 px) x `rows` output rows (<= 8).  All source rows the strip needs
+// (<= kResizeSrcRows) are requested up front: three aligned dwords per lane and row, shifted to the lane's
+// window by v_alignbyte, the 4+4 taps gathered by two v_perm_b32 with per-lane constant selectors (host
+// quad table).  Each source row's horizontal sums are computed once and folded into every output row
+// that uses it (wave-uniform tests on the y table).  3 dword loads per lane and source row instead of
+// 20 byte/short loads per output row, and one round of memory latency per strip.
+constexpr int kResizeSrcRows = 12;
+
+__global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, size_t pyrFrameBytes,
+                                                     unsigned long long srcOff, int srcPitch,
+                                                     unsigned long long dstOff, int dstPitch, int nq, int dh, int rows,
+                                                     const ResizeQuad* __restrict__ qtab, const short4* __restrict__ ytab)
+{
+    const int qi = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int strip = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const int yBeg = strip * rows;
+    if (yBeg >= dh) return;
+    const int yEnd = min(yBeg + rows, dh);
+    const bool live = qi < nq;
+    const ResizeQuad e = qtab[live ? qi : 0];
+    const uint32_t b = e.bOff & 0xFFFFFF, off = e.bOff >> 24;
+    const uint8_t* S = pyr + (size_t)blockIdx.z * pyrFrameBytes + srcOff;
+    short4 ty[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ty[r] = ytab[min(yBeg + r, yEnd - 1)];       // wave-uniform
+    const int sBeg = ty[0].x, sEnd = ytab[yEnd - 1].y;
+    uint32_t A[kResizeSrcRows], B[kResizeSrcRows], C[kResizeSrcRows];
+#pragma unroll
+    for (int j = 0; j < kResizeSrcRows; ++j) {
+        const uint32_t* r = (const uint32_t*)(S + (size_t)min(sBeg + j, sEnd) * srcPitch) + b;
+        A[j] = r[0]; B[j] = r[1]; C[j] = r[2];
+    }
+    int acc[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[r][i] = 2;
+#pragma unroll
+    for (int j = 0; j < kResizeSrcRows; ++j) {
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(B[j], A[j], off), w1 = __builtin_amdgcn_alignbyte(C[j], B[j], off);
+        const uint32_t p0 = __builtin_amdgcn_perm(w1, w0, e.sel0), p1 = __builtin_amdgcn_perm(w1, w0, e.sel1);
+        int T[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) T[i] = ((int)((p0 >> (8 * i)) & 255u) * e.a0[i] + (int)((p1 >> (8 * i)) & 255u) * e.a1[i]) >> 4;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (yBeg + r < yEnd) {
+                if (ty[r].x - sBeg == j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[r][i] += (ty[r].z * T[i]) >> 16;
+                }
+                if (ty[r].y - sBeg == j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[r][i] += (ty[r].w * T[i]) >> 16;
+                }
+            }
+        }
+    }
+    uint8_t* D = pyr + (size_t)blockIdx.z * pyrFrameBytes + dstOff + 4 * qi - kPadX;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (live && yBeg + r < yEnd) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v |= (uint32_t)((acc[r][i] >> 2) & 255) << (8 * i);
+            *(uint32_t*)(D + (size_t)(yBeg + r) * dstPitch) = v;
+        }
+    }
+}
+
 void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int level, const int16_t* tabs,
-                   size_t xTabOff, size_t yTabOff, int batch, hipStream_t s)
+                   size_t xTabOff, size_t yTabOff, size_t quadTabOff, int mode, int rows, int batch, hipStream_t s)
 {
     const int dw = kl.w[level], dh = kl.h[level];
-    dim3 grid((dw + 255) / 256, (dh + 3) / 4, batch);
+    if (mode == 1) {
+        const int nq = (dw + 2 * kPadX + 3) / 4;
+        dim3 grid((nq + 63) / 64, (dh + 4 * rows - 1) / (4 * rows), batch);
+        hipLaunchKernelGGL(k_resize_quad, grid, dim3(256), 0, s, pyr, pyrFrameBytes,
+                           kl.offset[level - 1], kl.pitch[level - 1], kl.offset[level], kl.pitch[level], nq, dh, rows,
+                           (const ResizeQuad*)(tabs + quadTabOff), (const short4*)(tabs + yTabOff));
+        return;
+    }
+    dim3 grid((dw + 2 * kPadX + 255) / 256, (dh + 3) / 4, batch);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, pyr, pyrFrameBytes,
                        kl.offset[level - 1], kl.pitch[level - 1], kl.offset[level], kl.pitch[level], dw, dh,
-                       (const short4*)(tabs + xTabOff), (const short4*)(tabs + yTabOff));
+                       (const short4*)(tabs + xTabOff), (const short4*)(tabs + yTabOff), mode == 2 ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -332,47 +418,110 @@ void launch_compact(const KLevels& kl, int cellsPerFrame, size_t slotsPerFrame, 
 
 // ---------------------------------------------------------------------------
 // GaussianBlur 7x7 sigma 2, BORDER_REFLECT_101 on the isolated level (src/Feature.cpp:547-548,
-// SURVEY App. A4): separable, 8-bit kernel {18,34,49,55,49,34,18}, row sums <= 65535 (u16 in
-// LDS), column pass (sum + 32768) >> 16 saturated.  Tile = 64 x 16 outputs per workgroup.
-__device__ __forceinline__ int refl101(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * n - 2 - p : p; }
-
-__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, size_t pyrFrameBytes, KLevels kl)
+// SURVEY App. A4): separable, 8-bit kernel {18,34,49,55,49,34,18}; row sums <= 65535, column pass
+// (sum + 32768) >> 16 saturated.
+//
+// Streaming form, no LDS: a half-wave (32 lanes) owns a strip of 120 output pixels x R rows and
+// walks down the rows.  Each lane loads ONE dword (4 pixels) per row; its left/right neighbours'
+// dwords arrive by DPP wave shifts (lanes 0 and 31 of the strip are halo lanes that only feed
+// their neighbours).  Row pass: 6 v_alignbyte + 8 v_dot4_u32_u8 for 4 pixels.  The last 7 rows
+// of row sums live in registers (static indices through a 7-step unrolled body); column pass in
+// 32-bit v_mad_u32_u24; one dword store per lane and row.  HBM traffic = the algorithmic
+// 2 bytes per pixel plus a 6-row halo per strip and the two halo lanes.
+// rows carry 4 reflect-101 pad columns on both sides, so every lane that feeds an output loads a plain
+// dword; lanes further out (x > w+3) are clamped onto the last pad dword and feed nobody
+__device__ __forceinline__ uint32_t blur_load4(const uint8_t* __restrict__ row, int x, int w)
 {
-    __shared__ uint8_t in[22][72];
-    __shared__ uint16_t rs[22][64];
-    const int tid = threadIdx.x, frame = blockIdx.y;
-    int level = 0;
-    while (level + 1 < kl.nlevels && (int)blockIdx.x >= kl.blurTileBase[level + 1]) ++level;
-    const int t = blockIdx.x - kl.blurTileBase[level];
-    const int ty = t / kl.blurTilesX[level], tx = t - ty * kl.blurTilesX[level];
-    const int w = kl.w[level], h = kl.h[level], pitch = kl.pitch[level];
-    const uint8_t* src = pyr + (size_t)frame * pyrFrameBytes + kl.offset[level];
-    uint8_t* dst = blur + (size_t)frame * pyrFrameBytes + kl.offset[level];
-    const int x0 = tx * 64, y0 = ty * 16;
-    for (int i = tid; i < 22 * 70; i += 256) {
-        const int r = i / 70, c = i - r * 70;
-        in[r][c] = src[(size_t)refl101(y0 + r - 3, h) * pitch + refl101(x0 + c - 3, w)];
-    }
-    __syncthreads();
-    for (int i = tid; i < 22 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &in[r][c];
-        rs[r][c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
-    }
-    __syncthreads();
-    for (int i = tid; i < 16 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        if (x0 + c < w && y0 + r < h) {
-            int s = 18 * (rs[r][c] + rs[r + 6][c]) + 34 * (rs[r + 1][c] + rs[r + 5][c]) + 49 * (rs[r + 2][c] + rs[r + 4][c]) + 55 * rs[r + 3][c];
-            s = (s + 32768) >> 16;
-            dst[(size_t)(y0 + r) * pitch + x0 + c] = (uint8_t)min(s, 255);
-        }
+    return *(const uint32_t*)(row + min(x, (w + 3) & ~3));
+}
+
+__device__ __forceinline__ void blur_rowsum(uint32_t d1, uint32_t (&r)[4])
+{
+    const uint32_t d0 = __builtin_amdgcn_update_dpp(0u, d1, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1's dword
+    const uint32_t d2 = __builtin_amdgcn_update_dpp(0u, d1, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1's dword
+    const uint32_t WLO = 18u | (34u << 8) | (49u << 16) | (55u << 24);                // x-3 .. x
+    const uint32_t WHI = 49u | (34u << 8) | (18u << 16);                              // x+1 .. x+3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = i == 3 ? d1 : __builtin_amdgcn_alignbyte(d1, d0, i + 1);
+        const uint32_t hi = i == 3 ? d2 : __builtin_amdgcn_alignbyte(d2, d1, i + 1);
+        r[i] = __builtin_amdgcn_udot4(lo, WLO, __builtin_amdgcn_udot4(hi, WHI, 0u, false), false);
     }
 }
 
-void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, int batch, hipStream_t s)
+__device__ __forceinline__ uint32_t blur_col4(const uint32_t (&a)[4], const uint32_t (&b)[4], const uint32_t (&c)[4],
+                                              const uint32_t (&d)[4], const uint32_t (&e)[4], const uint32_t (&f)[4],
+                                              const uint32_t (&g)[4])
 {
-    hipLaunchKernelGGL(k_blur, dim3(tilesPerFrame, batch), dim3(256), 0, s, pyr, blur, pyrFrameBytes, kl);
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t s = 18u * (a[i] + g[i]) + 32768u;
+        s += 34u * (b[i] + f[i]);
+        s += 49u * (c[i] + e[i]);
+        s += 55u * d[i];
+        out |= min(s >> 16, 255u) << (8 * i);
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, size_t pyrFrameBytes, KLevels kl)
+{
+    const int lane = threadIdx.x & 31;
+    const int strip = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int frame = blockIdx.y;
+    const bool live = strip < kl.blurStripBase[kl.nlevels];
+    int level = 0;
+    while (level + 1 < kl.nlevels && strip >= kl.blurStripBase[level + 1]) ++level;
+    const int t = live ? strip - kl.blurStripBase[level] : 0;
+    const int sy = t / kl.blurStripsX[level], sx = t - sy * kl.blurStripsX[level];
+    const int w = kl.w[level], h = kl.h[level], pitch = kl.pitch[level];
+    const int iters = live ? kl.blurIters[level] : 0;
+    const int rows = 7 * iters - 6;
+    const uint8_t* src = pyr + (size_t)frame * pyrFrameBytes + kl.offset[level];
+    uint8_t* dst = blur + (size_t)frame * pyrFrameBytes + kl.offset[level];
+    const int x = sx * 120 - 4 + 4 * lane;                 // first of this lane's 4 pixels
+    const int y0 = sy * rows;
+    const bool writer = lane >= 1 && lane <= 30 && x < w;
+    uint32_t r0[4], r1[4], r2[4], r3[4], r4[4], r5[4], r6[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r0[i] = r1[i] = r2[i] = r3[i] = r4[i] = r5[i] = r6[i] = 0;
+    // step s consumes input row y0-3+s and (from s >= 6) emits output row y0+s-6.  The 7 loads of
+    // the NEXT iteration are issued before the current one is processed (latency hiding).
+#define BLUR_LOAD(S0, S) blur_load4(src + (size_t)min(max(refl101(y0 - 3 + (S0) + (S), h), 0), h - 1) * pitch, x, w)
+#define BLUR_STEP(S, RN, A, B, C, D, E, F, G)                                                        \
+    {                                                                                                \
+        blur_rowsum(cur[S], RN);                                                                     \
+        const int yout = y0 + s0 + (S) - 6;                                                          \
+        if (s0 + (S) >= 6 && writer && yout < h)                                                     \
+            *(uint32_t*)(dst + (size_t)yout * pitch + x) = blur_col4(A, B, C, D, E, F, G);           \
+    }
+    uint32_t cur[7], nxt[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { cur[i] = iters > 0 ? BLUR_LOAD(0, i) : 0u; nxt[i] = 0; }
+    for (int it = 0; it < iters; ++it) {
+        const int s0 = it * 7;
+        if (it + 1 < iters) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) nxt[i] = BLUR_LOAD(s0 + 7, i);
+        }
+        BLUR_STEP(0, r0, r1, r2, r3, r4, r5, r6, r0)
+        BLUR_STEP(1, r1, r2, r3, r4, r5, r6, r0, r1)
+        BLUR_STEP(2, r2, r3, r4, r5, r6, r0, r1, r2)
+        BLUR_STEP(3, r3, r4, r5, r6, r0, r1, r2, r3)
+        BLUR_STEP(4, r4, r5, r6, r0, r1, r2, r3, r4)
+        BLUR_STEP(5, r5, r6, r0, r1, r2, r3, r4, r5)
+        BLUR_STEP(6, r6, r0, r1, r2, r3, r4, r5, r6)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) cur[i] = nxt[i];
+    }
+#undef BLUR_LOAD
+#undef BLUR_STEP
+}
+
+void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int stripsPerFrame, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_blur, dim3((stripsPerFrame + 7) / 8, batch), dim3(256), 0, s, pyr, blur, pyrFrameBytes, kl);
 }
 
 // ---------------------------------------------------------------------------

@@ -24,7 +24,7 @@ class ORBextractor:
         self._last = None
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
+        if getattr(self, "_h", None) and self._h.value and L is not None and L.lib is not None:
             L.lib().ssvio_orb_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -19,7 +19,7 @@ class FeatureMatching:
         L.check(L.lib().ssvio_matcher_create(self.mTh_, self.mNNRatio_, device, C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
+        if getattr(self, "_h", None) and self._h.value and L is not None and L.lib is not None:
             L.lib().ssvio_matcher_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -47,6 +47,19 @@ def test_stages_and_end_to_end(mods, w, h, nf):
     g.close()
 
 
+@pytest.mark.parametrize("sf,nl,w,h", [(1.5, 5, 640, 480), (2.6, 3, 800, 600), (1.1, 12, 512, 384), (2.0, 3, 640, 480)])
+def test_other_scale_factors(mods, sf, nl, w, h):
+    """scale factors outside 1.2: the quad resize kernel up to ~2, the generic one beyond"""
+    S, synth, O = mods
+    img = synth.texture(55, h, w)
+    g = S.ORBextractor(800, sf, nl, 20, 7); c = O.Extractor(800, sf, nl, 20, 7)
+    kps, desc = g.Extract(img)
+    _cmp_frame(O, g, c, img, kps, desc)
+    for l in range(nl):
+        assert np.array_equal(g.debug_level_image(l), c.level_image(l)), "pyramid level %d" % l
+    g.close()
+
+
 def test_tables_match_oracle(mods):
     S, synth, O = mods
     for nf, sf, nl in [(1200, 1.2, 8), (500, 1.2, 8), (4000, 1.2, 8), (1000, 1.5, 5), (777, 1.1, 12)]:

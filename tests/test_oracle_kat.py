@@ -68,6 +68,13 @@ def test_resize_identity_constant_and_ramp(oracle):
     assert np.array_equal(out, exp.astype(np.uint8))
 
 
+def test_resize_exact_half_is_inter_area(oracle):
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (40, 60), dtype=np.uint8).astype(np.int64)
+    exp = (a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(oracle.resize_linear(a.astype(np.uint8), 30, 20), exp.astype(np.uint8))
+
+
 def test_blur_impulse_is_kernel_outer_product(oracle):
     k = np.array(KAT["gauss_kernel_q8"], np.int64)
     img = np.zeros((21, 21), np.uint8); img[10, 10] = 255
