@@ -36,7 +36,7 @@ def level_pixels(ex, w, h):
 def algorithmic_bytes(kernel, B, px, nkp_total, pairs_rows):
     """SURVEY.md §8(d) per-unit figures split per kernel; bytes for ONE launch over the batch."""
     P = sum(px)
-    if kernel == "k_fast_cells":
+    if kernel in ("k_fast_cells", "k_fast_score+nms"):
         return B * P                                   # every pyramid pixel read once
     if kernel == "k_blur":
         return B * 2 * P                               # read level, write blurred level

@@ -147,7 +147,7 @@ struct ssvio_orb {
     int kpCap = 0;                 // keypoints per frame
     int candCap = 0;               // candidates per frame (all levels)
     size_t inBytes = 0;
-    uint8_t* d_in = nullptr; uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr;
+    uint8_t* d_in = nullptr; uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; uint8_t* d_score = nullptr;
     int16_t* d_tabs = nullptr; std::vector<size_t> xTabOff, yTabOff, qTabOff; std::vector<char> quadOk; std::vector<int> resizeRows;
     uint32_t* d_slots = nullptr; int* d_cellCount = nullptr;
     uint32_t* d_cand = nullptr; int* d_candCount = nullptr;
@@ -162,7 +162,7 @@ struct ssvio_orb {
 
 static void orb_free_buffers(ssvio_orb* h)
 {
-    dfree(h->d_in); dfree(h->d_pyr); dfree(h->d_blur); dfree(h->d_tabs); dfree(h->d_slots); dfree(h->d_cellCount);
+    dfree(h->d_in); dfree(h->d_pyr); dfree(h->d_blur); dfree(h->d_score); dfree(h->d_tabs); dfree(h->d_slots); dfree(h->d_cellCount);
     dfree(h->d_cand); dfree(h->d_candCount); dfree(h->d_kpIn); dfree(h->d_kpCount); dfree(h->d_kpOut); dfree(h->d_desc);
     hfree(h->h_cand); hfree(h->h_candCount); hfree(h->h_kpIn); hfree(h->h_kpCount);
     h->batchCap = 0; h->inBytes = 0; h->haveResults = false;
@@ -177,11 +177,13 @@ static void fill_klevels(const PyramidGeom& g, KLevels& k)
         k.w[l] = L.w; k.h[l] = L.h; k.pitch[l] = L.pitch; k.offset[l] = L.offset;
         k.nCols[l] = L.nCols; k.nRows[l] = L.nRows; k.wCell[l] = L.wCell; k.hCell[l] = L.hCell;
         k.cellBase[l] = L.cellBase; k.slotCap[l] = L.slotCap; k.slotBase[l] = L.slotBase;
+        k.fastTileBase[l] = L.fastTileBase; k.fastTilesX[l] = L.fastTilesX;
         k.blurStripBase[l] = L.blurStripBase; k.blurStripsX[l] = L.blurStripsX; k.blurIters[l] = L.blurIters;
         k.scale[l] = L.scale; k.kpSize[l] = L.kpSize;
     }
     k.cellBase[g.nlevels] = g.cellsPerFrame;
     k.blurStripBase[g.nlevels] = g.blurStripsPerFrame;
+    k.fastTileBase[g.nlevels] = g.fastTilesPerFrame;
 }
 
 // (re)allocate for a w x h x batch configuration
@@ -223,6 +225,7 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
         if (h->candCap == 0) h->candCap = std::max(8192, 8 * h->tab.nfeatures);
         SSVIO_HIP(hipMalloc(&h->d_pyr, B * g.frameBytes));
         SSVIO_HIP(hipMalloc(&h->d_blur, B * g.frameBytes));
+        SSVIO_HIP(hipMalloc(&h->d_score, B * g.frameBytes));
         SSVIO_HIP(hipMemsetAsync(h->d_pyr, 0, B * g.frameBytes, h->stream));
         SSVIO_HIP(hipMemsetAsync(h->d_blur, 0, B * g.frameBytes, h->stream));
         SSVIO_HIP(hipMalloc(&h->d_slots, B * g.slotsPerFrame * sizeof(uint32_t)));
@@ -269,9 +272,9 @@ static int orb_run(ssvio_orb* h, int batch)
         launch_resize(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], h->qTabOff[l], (int)h->quadOk[l], h->resizeRows[l], batch, s);
     }
     {
-        ProfScope p(h->prof, "k_fast_cells", s);
-        launch_fast(h->d_pyr, g.frameBytes, h->kl, g.cellsPerFrame, g.slotsPerFrame, h->tab.iniTh, h->tab.minTh,
-                    h->d_slots, h->d_cellCount, batch, s);
+        ProfScope p(h->prof, "k_fast_score+nms", s);
+        launch_fast(h->d_pyr, h->d_score, g.frameBytes, h->kl, g.fastTilesPerFrame, g.cellsPerFrame, g.slotsPerFrame,
+                    h->tab.iniTh, h->tab.minTh, h->d_slots, h->d_cellCount, batch, s);
     }
     for (int attempt = 0;; ++attempt) {
         {

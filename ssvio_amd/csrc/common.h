@@ -39,6 +39,7 @@ struct LevelGeom {
     int quota;                // mnFeaturesPerLevel
     float scale;              // mvScaleFactor
     int kpSize;               // (int)(15*scale)
+    int fastTileBase, fastTilesX, fastTilesY;   // k_fast_score tiles (64 x 32 px)
     int blurStripBase, blurStripsX, blurStripsY, blurIters;   // k_blur strips: 120 px wide, 7*blurIters-6 rows tall
     size_t tabOffset;         // offset (in shorts) of this level's resize tables
 };
@@ -51,6 +52,7 @@ struct PyramidGeom {
     int cellsPerFrame = 0;
     size_t slotsPerFrame = 0;
     int blurStripsPerFrame = 0;
+    int fastTilesPerFrame = 0;
     int maxQuotaSum = 0;
 };
 
@@ -64,6 +66,7 @@ struct KLevels {
     int slotCap[kMaxLevels];
     unsigned long long slotBase[kMaxLevels];
     int blurStripBase[kMaxLevels + 1], blurStripsX[kMaxLevels], blurIters[kMaxLevels];
+    int fastTileBase[kMaxLevels + 1], fastTilesX[kMaxLevels];
     float scale[kMaxLevels];
     int kpSize[kMaxLevels];
 };
@@ -118,8 +121,8 @@ void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frame
                       uint8_t* pyr, size_t pyrFrameBytes, int pitch0, hipStream_t s);
 void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int level, const int16_t* tabs,
                    size_t xTabOff, size_t yTabOff, size_t quadTabOff, int mode /*0 generic, 1 quad, 2 area 2x2*/, int rows, int batch, hipStream_t s);
-void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int cellsPerFrame, size_t slotsPerFrame,
-                 int iniTh, int minTh, uint32_t* slots, int* cellCount, int batch, hipStream_t s);
+void launch_fast(const uint8_t* pyr, uint8_t* score, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, int cellsPerFrame,
+                 size_t slotsPerFrame, int iniTh, int minTh, uint32_t* slots, int* cellCount, int batch, hipStream_t s);
 void launch_compact(const KLevels& kl, int cellsPerFrame, size_t slotsPerFrame, const uint32_t* slots, const int* cellCount,
                     uint32_t* cand, int candCap, int* candCount /*[batch][kMaxLevels+1]*/, int batch, hipStream_t s);
 void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int stripsPerFrame, int batch, hipStream_t s);

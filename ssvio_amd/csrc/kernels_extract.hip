@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
 // A wave owns 64 output quads (256 px) x `rows` output rows (<= 8).  All source rows the strip needs
 // (<= kResizeSrcRows) are requested up front: three aligned dwords per lane and row, shifted to the lane's
 // window by v_alignbyte, the 4+4 taps gathered by two v_perm_b32 with per-lane constant selectors (host
-// quad table).  Each source row's horizontal sums are computed once and folded into every output row
-// that uses it (wave-uniform tests on the y table).  3 dword loads per lane and source row instead of
-// 20 byte/short loads per output row, and one round of memory latency per strip.
+// quad table).  The source rows are then consumed in order; an output row is finished as soon as its
+// second source row (always its first row or the one after it) has been reduced, so only the previous
+// and the current row's horizontal sums are live and all control flow is wave-uniform and short.
 constexpr int kResizeSrcRows = 12;
 
 __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, size_t pyrFrameBytes,
@@ -127,51 +127,38 @@ __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, 
     const ResizeQuad e = qtab[live ? qi : 0];
     const uint32_t b = e.bOff & 0xFFFFFF, off = e.bOff >> 24;
     const uint8_t* S = pyr + (size_t)blockIdx.z * pyrFrameBytes + srcOff;
-    short4 ty[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) ty[r] = ytab[min(yBeg + r, yEnd - 1)];       // wave-uniform
-    const int sBeg = ty[0].x, sEnd = ytab[yEnd - 1].y;
+    uint8_t* D = pyr + (size_t)blockIdx.z * pyrFrameBytes + dstOff + 4 * qi - kPadX;
+    const int sBeg = ytab[yBeg].x, sEnd = ytab[yEnd - 1].y;                   // wave-uniform
     uint32_t A[kResizeSrcRows], B[kResizeSrcRows], C[kResizeSrcRows];
 #pragma unroll
     for (int j = 0; j < kResizeSrcRows; ++j) {
         const uint32_t* r = (const uint32_t*)(S + (size_t)min(sBeg + j, sEnd) * srcPitch) + b;
         A[j] = r[0]; B[j] = r[1]; C[j] = r[2];
     }
-    int acc[8][4];
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[r][i] = 2;
+    int y = yBeg;                                        // next output row to finish (uniform)
+    short4 ty = ytab[y];
+    int Tp[4] = {0, 0, 0, 0}, Tc[4];
 #pragma unroll
     for (int j = 0; j < kResizeSrcRows; ++j) {
         const uint32_t w0 = __builtin_amdgcn_alignbyte(B[j], A[j], off), w1 = __builtin_amdgcn_alignbyte(C[j], B[j], off);
         const uint32_t p0 = __builtin_amdgcn_perm(w1, w0, e.sel0), p1 = __builtin_amdgcn_perm(w1, w0, e.sel1);
-        int T[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) T[i] = ((int)((p0 >> (8 * i)) & 255u) * e.a0[i] + (int)((p1 >> (8 * i)) & 255u) * e.a1[i]) >> 4;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (yBeg + r < yEnd) {
-                if (ty[r].x - sBeg == j) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[r][i] += (ty[r].z * T[i]) >> 16;
-                }
-                if (ty[r].y - sBeg == j) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[r][i] += (ty[r].w * T[i]) >> 16;
-                }
-            }
-        }
-    }
-    uint8_t* D = pyr + (size_t)blockIdx.z * pyrFrameBytes + dstOff + 4 * qi - kPadX;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        if (live && yBeg + r < yEnd) {
+        for (int i = 0; i < 4; ++i) Tc[i] = ((int)((p0 >> (8 * i)) & 255u) * e.a0[i] + (int)((p1 >> (8 * i)) & 255u) * e.a1[i]) >> 4;
+        while (y < yEnd && ty.y - sBeg == j) {           // rows whose second source row is row j
+            const bool same = ty.x == ty.y;              // clamped at the bottom edge: both taps on one row
             uint32_t v = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v |= (uint32_t)((acc[r][i] >> 2) & 255) << (8 * i);
-            *(uint32_t*)(D + (size_t)(yBeg + r) * dstPitch) = v;
+            for (int i = 0; i < 4; ++i) {
+                const int t0 = same ? Tc[i] : Tp[i];
+                const int r = (((ty.z * t0) >> 16) + ((ty.w * Tc[i]) >> 16) + 2) >> 2;
+                v |= (uint32_t)(r & 255) << (8 * i);
+            }
+            if (live) *(uint32_t*)(D + (size_t)y * dstPitch) = v;
+            ++y;
+            ty = ytab[min(y, dh - 1)];
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Tp[i] = Tc[i];
     }
 }
 
@@ -194,177 +181,261 @@ void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int le
 }
 
 // ---------------------------------------------------------------------------
-// FAST-9/16 + score + cell-local NMS + ini/min threshold fallback; one workgroup per
-// 30-px grid cell (src/Feature.cpp:851-892 with cv::FAST per SURVEY App. A3).
+// FAST-9/16 (src/Feature.cpp:851-892 with cv::FAST per SURVEY App. A3) in two kernels.
 //
 // cv::FAST's score of a corner is  s = max(maxmin_dark, maxmin_bright) - 1  where
-// maxmin_dark = max over the 16 arcs of 9 ring pixels of min(v - ring), and it does
-// not depend on the threshold; pixel p is a corner at threshold T  <=>  s(p) >= T.
-// So one score map serves both thresholds: M_T(q) = s(q) >= T ? s(q) : 0, and p is
-// kept iff s(p) >= T and s(p) > M_T(q) for its 8 neighbours inside the cell window's
-// tested interior (everything else counts as 0).
-constexpr int kTileW = 72;   // >= 65 (max window) rounded so rows are dword aligned
-constexpr int kTileH = 66;
-constexpr int kScW = 68;     // interior (<= 59) + 1-px zero rim each side, padded
+// maxmin_dark = max over the 16 arcs of 9 ring pixels of min(v - ring); it does not depend on the
+// threshold, and pixel p is a corner at threshold T  <=>  s(p) >= T.  The score of a pixel only
+// needs its own radius-3 ring, which always lies inside the window of the cell that tests the
+// pixel, so the score map is independent of the 30-px cell grid:
+//   k_fast_score  dense score map of a level (0 where s < min(iniTh,minTh) or outside the tested
+//                 region [19, w-20] x [19, h-20]), 64x32-pixel tiles;
+//   k_fast_nms    per cell: M_T(q) = s(q) >= T ? s(q) : 0 restricted to the cell's tested interior
+//                 (everything else counts as 0, as cv::FAST's untested rim does), keep p iff
+//                 s(p) >= T and s(p) > M_T(q) for its 8 neighbours; T = iniTh, or minTh when the
+//                 iniTh list of the cell is empty (:875); emit in raster order.
+constexpr int kFtW = 64, kFtH = 32;          // output tile of k_fast_score
+constexpr int kFtPitch = 72;                 // LDS row: x0-4 .. x0+67
+constexpr int kFtRows = kFtH + 6;
 
-__device__ __forceinline__ int arc9_maxmin(const int (&d)[16])
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+// max over the 16 circular arcs of 9 of min(d): both polarities at once in packed i16
+// (.x = v - ring -> dark arcs, .y = ring - v -> bright arcs)
+__device__ __forceinline__ short2v arc9_maxmin_pk(const short2v (&p)[16])
 {
-    int m2[16], m4[16], m8[16], r = -1024;
+    short2v m2[16], m4[16], m8[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m2[k] = min(d[k], d[(k + 1) & 15]);
+    for (int k = 0; k < 16; ++k) m2[k] = __builtin_elementwise_min(p[k], p[(k + 1) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+    for (int k = 0; k < 16; ++k) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m8[k] = min(m4[k], m4[(k + 4) & 15]);
+    for (int k = 0; k < 16; ++k) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
+    short2v r = __builtin_elementwise_min(m8[0], p[8]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) r = max(r, min(m8[k], d[(k + 8) & 15]));
+    for (int k = 1; k < 16; ++k) r = __builtin_elementwise_max(r, __builtin_elementwise_min(m8[k], p[(k + 8) & 15]));
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t pyrFrameBytes, KLevels kl,
-                                                    int cellsPerFrame, size_t slotsPerFrame, int iniTh, int minTh,
-                                                    uint32_t* __restrict__ slots, int* __restrict__ cellCount)
+__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
+                                                    size_t pyrFrameBytes, KLevels kl, int tLow)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH * kTileW];
-    __shared__ __attribute__((aligned(16))) uint8_t sc[kScW * kScW];
-    __shared__ uint16_t queue[kMaxCellDim * kMaxCellDim];
-    __shared__ unsigned long long rowmask[kMaxCellDim];
-    __shared__ int rowoff[kMaxCellDim + 1];
-    __shared__ int qn, nIni;
-
-    const int tid = threadIdx.x;
-    const int cell = blockIdx.x, frame = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kFtRows * kFtPitch / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t sc[kFtW * kFtH / 4];
+    __shared__ uint16_t queue[kFtW * kFtH];
+    __shared__ int qn;
+    const int tid = threadIdx.x, frame = blockIdx.y;
     int level = 0;
-    while (level + 1 < kl.nlevels && cell >= kl.cellBase[level + 1]) ++level;
-    const int lc = cell - kl.cellBase[level];
-    const int ci = lc / kl.nCols[level], cj = lc - ci * kl.nCols[level];
-    const int wCell = kl.wCell[level], hCell = kl.hCell[level];
-    const int maxBX = kl.w[level] - kMinBorder, maxBY = kl.h[level] - kMinBorder;
-    const int iniX = kMinBorder + cj * wCell, iniY = kMinBorder + ci * hCell;
-    int* myCount = cellCount + (size_t)frame * cellsPerFrame + cell;
-    // the reference skips these cells entirely (src/Feature.cpp:856, :866)
-    if (iniY >= maxBY - 3 || iniX >= maxBX - 6) { if (tid == 0) *myCount = 0; return; }
-    const int ww = min(iniX + wCell + 6, maxBX) - iniX, wh = min(iniY + hCell + 6, maxBY) - iniY;
-    const int iw = ww - 6, ih = wh - 6;                 // tested interior (cv::FAST rows/cols 3..n-4)
-    if (iw <= 0 || ih <= 0) { if (tid == 0) *myCount = 0; return; }
-
-    const int pitch = kl.pitch[level];
-    const uint8_t* img = pyr + (size_t)frame * pyrFrameBytes + kl.offset[level] + (size_t)iniY * pitch + iniX;
-    for (int i = tid; i < wh * ww; i += 256) {
-        const int y = i / ww, x = i - y * ww;
-        tile[y * kTileW + x] = img[(size_t)y * pitch + x];
-    }
-    for (int i = tid; i < kScW * kScW / 4; i += 256) ((uint32_t*)sc)[i] = 0;
-    if (tid < kMaxCellDim) rowmask[tid] = 0;
-    if (tid == 0) { qn = 0; nIni = 0; }
-    __syncthreads();
-
-    const int tLow = min(iniTh, minTh);
-    // phase 1: high-speed rejection on the 4 compass pixels; survivors are queued
-    for (int p0 = 0; p0 < iw * ih; p0 += 256) {
-        const int p = p0 + tid;
-        bool pass = false;
-        if (p < iw * ih) {
-            const int iy = p / iw, ix = p - iy * iw;
-            const uint8_t* c = tile + (iy + 3) * kTileW + ix + 3;
-            const int v = c[0];
-            const int lo = v - tLow, hi = v + tLow;
-            const int r0 = c[3 * kTileW], r8 = c[-3 * kTileW], r4 = c[3], r12 = c[-3];
-            const int c0 = (r0 < lo ? 1 : 0) | (r0 > hi ? 2 : 0), c8 = (r8 < lo ? 1 : 0) | (r8 > hi ? 2 : 0);
-            const int c4 = (r4 < lo ? 1 : 0) | (r4 > hi ? 2 : 0), c12 = (r12 < lo ? 1 : 0) | (r12 > hi ? 2 : 0);
-            pass = ((c0 | c8) & (c4 | c12)) != 0;
+    while (level + 1 < kl.nlevels && (int)blockIdx.x >= kl.fastTileBase[level + 1]) ++level;
+    const int t = blockIdx.x - kl.fastTileBase[level];
+    const int tyi = t / kl.fastTilesX[level], txi = t - tyi * kl.fastTilesX[level];
+    const int w = kl.w[level], h = kl.h[level], pitch = kl.pitch[level];
+    const int x0 = txi * kFtW, y0 = tyi * kFtH;
+    const uint8_t* img = pyr + (size_t)frame * pyrFrameBytes + kl.offset[level];
+    const int xMaxLoad = (w + 56) & ~3;                    // last dword that is still inside the row's slack
+    {
+        uint32_t ld[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = tid + k * 256;
+            const int r = (i * 3641) >> 16, c = i - r * (kFtPitch / 4);        // i / 18 for i < 1100
+            const int yy = min(max(y0 - 3 + r, 0), h - 1);
+            ld[k] = i < kFtRows * (kFtPitch / 4) ? *(const uint32_t*)(img + (size_t)yy * pitch + min(x0 - 4 + 4 * c, xMaxLoad)) : 0u;
         }
-        const unsigned long long m = __ballot(pass);
-        if (m) {
-            int base = 0;
-            const int lane = tid & 63;
-            if (lane == 0) base = atomicAdd(&qn, __popcll(m));
-            base = __shfl(base, 0);
-            if (pass) queue[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)p;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int i = tid + k * 256; if (i < kFtRows * (kFtPitch / 4)) tile[i] = ld[k]; }
+    }
+    for (int i = tid; i < kFtW * kFtH / 4; i += 256) sc[i] = 0;
+    if (tid == 0) qn = 0;
+    __syncthreads();
+    const uint8_t* tb = (const uint8_t*)tile;
+    // phase 1, packed: a 9-arc always contains two ADJACENT compass pixels (ring 0,4,8,12); "some adjacent
+    // compass pair in one class" == (down|up) & (left|right) per class.  Two pixels per packed-i16 register:
+    // darker-by-more-than-T mask = (T - (v - n)) >> 15, brighter mask = (T + (v - n)) >> 15.
+    unsigned flags = 0;                                     // bit (4k+i): pixel i of this thread's quad k survives
+    const short2v T2 = short2v{(short)tLow, (short)tLow};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = tid + k * 256, qc = q & 15, r = q >> 4;
+        const uint32_t C = tile[(r + 3) * (kFtPitch / 4) + qc + 1], L = tile[(r + 3) * (kFtPitch / 4) + qc],
+                       R = tile[(r + 3) * (kFtPitch / 4) + qc + 2];
+        const uint32_t U = tile[r * (kFtPitch / 4) + qc + 1], D = tile[(r + 6) * (kFtPitch / 4) + qc + 1];
+        const uint32_t lw = __builtin_amdgcn_alignbyte(C, L, 1);      // bytes x-3 .. x
+        const uint32_t rw = __builtin_amdgcn_alignbyte(R, C, 3);      // bytes x+3 .. x+6
+        const int y = y0 + r;
+        const bool rowOk = y >= kEdge && y <= h - kEdge - 1;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const uint32_t sel = hlf ? 0x0c030c02u : 0x0c010c00u;      // bytes (0,1) or (2,3) -> two u16
+            auto pk = [&](uint32_t x) { return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, x, sel)); };
+            const short2v v = pk(C);
+            const short2v du = v - pk(U), dd = v - pk(D), dl = v - pk(lw), dr = v - pk(rw);
+            const short2v darkV = ((T2 - du) >> 15) | ((T2 - dd) >> 15), darkH = ((T2 - dl) >> 15) | ((T2 - dr) >> 15);
+            const short2v brtV = ((T2 + du) >> 15) | ((T2 + dd) >> 15), brtH = ((T2 + dl) >> 15) | ((T2 + dr) >> 15);
+            const uint32_t m = __builtin_bit_cast(uint32_t, (short2v)((darkV & darkH) | (brtV & brtH)));
+            const int xa = x0 + 4 * qc + 2 * hlf;
+            if (rowOk && (m & 1u) && xa >= kEdge && xa <= w - kEdge - 1) flags |= 1u << (4 * k + 2 * hlf);
+            if (rowOk && (m & 0x10000u) && xa + 1 >= kEdge && xa + 1 <= w - kEdge - 1) flags |= 1u << (4 * k + 2 * hlf + 1);
+        }
+    }
+    {   // one queue reservation per wave
+        const int lane = tid & 63;
+        const int cnt = __popc(flags);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o); if (lane >= o) incl += tt; }
+        const int tot = __shfl(incl, 63);
+        int base = 0;
+        if (tot) {
+            if (lane == 63) base = atomicAdd(&qn, tot);
+            base = __shfl(base, 63) + incl - cnt;
+            unsigned f = flags;
+            while (f) {
+                const int bit = __ffs(f) - 1; f &= f - 1;
+                const int q = tid + (bit >> 2) * 256, qc = q & 15, r = q >> 4;
+                queue[base++] = (uint16_t)(r * kFtW + 4 * qc + (bit & 3));
+            }
         }
     }
     __syncthreads();
     const int nq = qn;
-    // phase 2: exact score for queued pixels
+    // phase 2: exact score of the queued pixels
     for (int q = tid; q < nq; q += 256) {
         const int p = queue[q];
-        const int iy = p / iw, ix = p - iy * iw;
-        const uint8_t* c = tile + (iy + 3) * kTileW + ix + 3;
+        const int ly = p >> 6, lx = p & 63;
+        const uint8_t* c = tb + (ly + 3) * kFtPitch + lx + 4;
         const int v = c[0];
-        int d[16];
-        d[0] = v - c[3 * kTileW];       d[1] = v - c[3 * kTileW + 1];   d[2] = v - c[2 * kTileW + 2];   d[3] = v - c[kTileW + 3];
-        d[4] = v - c[3];                d[5] = v - c[-kTileW + 3];      d[6] = v - c[-2 * kTileW + 2];  d[7] = v - c[-3 * kTileW + 1];
-        d[8] = v - c[-3 * kTileW];      d[9] = v - c[-3 * kTileW - 1];  d[10] = v - c[-2 * kTileW - 2]; d[11] = v - c[-kTileW - 3];
-        d[12] = v - c[-3];              d[13] = v - c[kTileW - 3];      d[14] = v - c[2 * kTileW - 2];  d[15] = v - c[3 * kTileW - 1];
-        const int a = arc9_maxmin(d);
+        short2v d[16];
+#define RING(K, OFF) { const int dd = v - c[OFF]; d[K] = short2v{(short)dd, (short)-dd}; }
+        RING(0, 3 * kFtPitch)      RING(1, 3 * kFtPitch + 1)   RING(2, 2 * kFtPitch + 2)   RING(3, kFtPitch + 3)
+        RING(4, 3)                 RING(5, -kFtPitch + 3)      RING(6, -2 * kFtPitch + 2)  RING(7, -3 * kFtPitch + 1)
+        RING(8, -3 * kFtPitch)     RING(9, -3 * kFtPitch - 1)  RING(10, -2 * kFtPitch - 2) RING(11, -kFtPitch - 3)
+        RING(12, -3)               RING(13, kFtPitch - 3)      RING(14, 2 * kFtPitch - 2)  RING(15, 3 * kFtPitch - 1)
+#undef RING
+        const short2v ab = arc9_maxmin_pk(d);
+        const int s = max((int)ab.x, (int)ab.y) - 1;
+        if (s >= tLow && s > 0) ((uint8_t*)sc)[p] = (uint8_t)s;
+    }
+    __syncthreads();
+    uint8_t* out = score + (size_t)frame * pyrFrameBytes + kl.offset[level];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = -d[k];
-        const int b = arc9_maxmin(d);
-        const int s = max(a, b) - 1;
-        if (s >= tLow && s > 0) sc[(iy + 1) * kScW + ix + 1] = (uint8_t)s;
+    for (int k = 0; k < 2; ++k) {
+        const int q = tid + k * 256, qc = q & 15, r = q >> 4;
+        if (y0 + r < h && x0 + 4 * qc < w + 4) *(uint32_t*)(out + (size_t)(y0 + r) * pitch + x0 + 4 * qc) = sc[q];
     }
-    __syncthreads();
-    // phase 3: NMS at both thresholds
-    int cntIni = 0;
-    for (int q = tid; q < nq; q += 256) {
-        const int p = queue[q];
-        const int iy = p / iw, ix = p - iy * iw;
-        const uint8_t* c = sc + (iy + 1) * kScW + ix + 1;
-        const int s = c[0];
-        int flags = 0;
-        if (s) {
-            const int n0 = c[-kScW - 1], n1 = c[-kScW], n2 = c[-kScW + 1], n3 = c[-1], n4 = c[1],
-                      n5 = c[kScW - 1], n6 = c[kScW], n7 = c[kScW + 1];
-            const int mAll = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-            // M_T(q) = n >= T ? n : 0, so  s > max_q M_T(q)  <=>  every neighbour is < T or < s
-            auto nmsAt = [&](int T) {
-                if (s < T) return false;
-                if (s > mAll) return true;
-                const int t1 = T - 1;   // neighbours <= t1 do not count
-                return (n0 <= t1 || n0 < s) && (n1 <= t1 || n1 < s) && (n2 <= t1 || n2 < s) && (n3 <= t1 || n3 < s) &&
-                       (n4 <= t1 || n4 < s) && (n5 <= t1 || n5 < s) && (n6 <= t1 || n6 < s) && (n7 <= t1 || n7 < s);
-            };
-            if (nmsAt(iniTh)) { flags |= 1; ++cntIni; }
-            if (nmsAt(minTh)) flags |= 2;
+}
+
+constexpr int kNmsPitch = 72;                // LDS bytes per staged score row (4 zero bytes + <= 17 dwords)
+constexpr int kNmsRows = kMaxCellDim + 2;
+
+__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ score, size_t pyrFrameBytes, KLevels kl,
+                                                  int cellsPerFrame, size_t slotsPerFrame, int iniTh, int minTh,
+                                                  uint32_t* __restrict__ slots, int* __restrict__ cellCount)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stage[4][kNmsRows * kNmsPitch / 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int frame = blockIdx.y;
+    const int cell = blockIdx.x * 4 + wv;
+    const bool have = cell < cellsPerFrame;
+    int level = 0;
+    while (level + 1 < kl.nlevels && cell >= kl.cellBase[level + 1]) ++level;
+    const int lc = have ? cell - kl.cellBase[level] : 0;
+    const int ci = lc / kl.nCols[level], cj = lc - ci * kl.nCols[level];
+    const int wCell = kl.wCell[level], hCell = kl.hCell[level];
+    const int maxBX = kl.w[level] - kMinBorder, maxBY = kl.h[level] - kMinBorder;
+    const int iniX = kMinBorder + cj * wCell, iniY = kMinBorder + ci * hCell;
+    // cells the reference skips (src/Feature.cpp:856, :866) have an empty tested interior anyway
+    const int iw = have ? max(min(iniX + wCell + 6, maxBX) - iniX - 6, 0) : 0;
+    const int ih = have ? max(min(iniY + hCell + 6, maxBY) - iniY - 6, 0) : 0;
+    const bool skip = !have || iniY >= maxBY - 3 || iniX >= maxBX - 6 || iw == 0 || ih == 0;
+    const int X0 = iniX + 3, Y0 = iniY + 3;                // first tested pixel
+    const int xa = X0 & ~3;                                // aligned start of the staged rows
+    const int nd = skip ? 0 : ((X0 + iw + 3) >> 2) - (xa >> 2);   // dwords per row (<= 17)
+    const int pitch = kl.pitch[level];
+    const uint8_t* src = score + (size_t)frame * pyrFrameBytes + kl.offset[level];
+    uint32_t* st = stage[wv];
+    uint8_t* sb = (uint8_t*)st;
+    // stage rows -1 .. ih (rows -1 and ih are zero), bytes outside [X0, X0+iw) zeroed; all of a lane's
+    // loads are issued before the first use (one round of memory latency per cell)
+    const int rowsStaged = skip ? 0 : ih + 2;
+    constexpr int kStageIters = (kNmsRows * (kNmsPitch / 4) + 63) / 64;
+    uint32_t sv[kStageIters];
+#pragma unroll
+    for (int k = 0; k < kStageIters; ++k) {
+        const int i = lane + 64 * k;
+        const int r = (i * 3641) >> 16, c = i - r * (kNmsPitch / 4);          // c = 0 is the zero dword left of xa
+        sv[k] = 0;
+        if (i < rowsStaged * (kNmsPitch / 4) && r >= 1 && r <= ih && c >= 1 && c <= nd)
+            sv[k] = *(const uint32_t*)(src + (size_t)(Y0 + r - 1) * pitch + xa + 4 * (c - 1));
+    }
+#pragma unroll
+    for (int k = 0; k < kStageIters; ++k) {
+        const int i = lane + 64 * k;
+        if (i < rowsStaged * (kNmsPitch / 4)) {
+            const int r = (i * 3641) >> 16, c = i - r * (kNmsPitch / 4);
+            const int xd = xa + 4 * (c - 1);
+            const int lo = X0 - xd, hi = X0 + iw - xd;                          // keep bytes lo <= b < hi
+            const uint32_t maskLo = lo <= 0 ? 0xFFFFFFFFu : (lo >= 4 ? 0u : 0xFFFFFFFFu << (8 * lo));
+            const uint32_t maskHi = hi >= 4 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : 0xFFFFFFFFu >> (8 * (4 - hi)));
+            st[i] = sv[k] & maskLo & maskHi;
         }
-        queue[q] = (uint16_t)(p | (flags << 13));
     }
-    if (cntIni) atomicAdd(&nIni, cntIni);
     __syncthreads();
-    const int want = nIni > 0 ? 1 : 2;          // src/Feature.cpp:875: retry at minTh only if the first list is empty
-    for (int q = tid; q < nq; q += 256) {
-        const int e = queue[q];
-        if ((e >> 13) & want) {
-            const int p = e & 0x1FFF;
-            const int iy = p / iw, ix = p - iy * iw;
-            atomicOr(&rowmask[iy], 1ull << ix);
+    unsigned long long mIni = 0, mMin = 0;
+    if (!skip && lane < ih) {
+        const uint8_t* row = sb + (lane + 1) * kNmsPitch + 4 + (X0 - xa);      // tested pixel ix at row[ix]
+        const uint32_t* rowd = st + (lane + 1) * (kNmsPitch / 4) + 1;
+        for (int c = 0; c < nd; ++c) {
+            if (rowd[c] == 0) continue;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int ix = 4 * c + bb - (X0 - xa);
+                const int s = (rowd[c] >> (8 * bb)) & 255;
+                if (s == 0) continue;
+                const uint8_t* p = row + ix;
+                const int n0 = p[-kNmsPitch - 1], n1 = p[-kNmsPitch], n2 = p[-kNmsPitch + 1], n3 = p[-1], n4 = p[1],
+                          n5 = p[kNmsPitch - 1], n6 = p[kNmsPitch], n7 = p[kNmsPitch + 1];
+                const int mAll = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+                auto nmsAt = [&](int T) {
+                    if (s < T) return false;
+                    if (s > mAll) return true;
+                    const int t1 = T - 1;      // neighbours <= t1 are not corners at T
+                    return (n0 <= t1 || n0 < s) && (n1 <= t1 || n1 < s) && (n2 <= t1 || n2 < s) && (n3 <= t1 || n3 < s) &&
+                           (n4 <= t1 || n4 < s) && (n5 <= t1 || n5 < s) && (n6 <= t1 || n6 < s) && (n7 <= t1 || n7 < s);
+                };
+                if (nmsAt(iniTh)) mIni |= 1ull << ix;
+                if (nmsAt(minTh)) mMin |= 1ull << ix;
+            }
         }
     }
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int y = 0; y < ih; ++y) { rowoff[y] = acc; acc += __popcll(rowmask[y]); }
-        rowoff[ih] = acc;
-        *myCount = acc;
-    }
-    __syncthreads();
-    if (tid < ih) {
-        unsigned long long m = rowmask[tid];
-        uint32_t* out = slots + (size_t)frame * slotsPerFrame + kl.slotBase[level] + (size_t)lc * kl.slotCap[level] + rowoff[tid];
-        while (m) {
-            const int ix = __ffsll((long long)m) - 1;
-            m &= m - 1;
+    // src/Feature.cpp:875: the minTh list is used only when the iniTh list of the cell is empty
+    const bool anyIni = __ballot(mIni != 0) != 0;
+    const unsigned long long m = anyIni ? mIni : mMin;
+    const int n = __popcll(m);
+    int incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o); if (lane >= o) incl += tt; }
+    const int total = __shfl(incl, 63);
+    if (have && lane == 0) cellCount[(size_t)frame * cellsPerFrame + cell] = total;
+    if (n) {
+        uint32_t* out = slots + (size_t)frame * slotsPerFrame + kl.slotBase[level] + (size_t)lc * kl.slotCap[level] + (incl - n);
+        const uint8_t* row = sb + (lane + 1) * kNmsPitch + 4 + (X0 - xa);
+        unsigned long long mm = m;
+        while (mm) {
+            const int ix = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
             // window-relative FAST coordinates (ix+3, iy+3) moved to the level's border frame (src/Feature.cpp:886-887)
-            const uint32_t x = ix + 3 + cj * wCell, y = tid + 3 + ci * hCell;
-            *out++ = x | (y << 12) | ((uint32_t)sc[(tid + 1) * kScW + ix + 1] << 24);
+            const uint32_t x = ix + 3 + cj * wCell, y = lane + 3 + ci * hCell;
+            *out++ = x | (y << 12) | ((uint32_t)row[ix] << 24);
         }
     }
 }
 
-void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int cellsPerFrame, size_t slotsPerFrame,
-                 int iniTh, int minTh, uint32_t* slots, int* cellCount, int batch, hipStream_t s)
+void launch_fast(const uint8_t* pyr, uint8_t* score, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, int cellsPerFrame,
+                 size_t slotsPerFrame, int iniTh, int minTh, uint32_t* slots, int* cellCount, int batch, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fast_cells, dim3(cellsPerFrame, batch), dim3(256), 0, s, pyr, pyrFrameBytes, kl,
+    hipLaunchKernelGGL(k_fast_score, dim3(tilesPerFrame, batch), dim3(256), 0, s, pyr, score, pyrFrameBytes, kl, min(iniTh, minTh));
+    hipLaunchKernelGGL(k_fast_nms, dim3((cellsPerFrame + 3) / 4, batch), dim3(256), 0, s, score, pyrFrameBytes, kl,
                        cellsPerFrame, slotsPerFrame, iniTh, minTh, slots, cellCount);
 }
 

@@ -4,7 +4,7 @@ f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 agg = collections.OrderedDict()
-for r in rows[len(rows)//2:]:
+for r in rows:
     k = (r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ssvio::", ""), r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
     agg.setdefault(k, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k, v in agg.items():
