@@ -36,7 +36,7 @@ def level_pixels(ex, w, h):
 def algorithmic_bytes(kernel, B, px, nkp_total, pairs_rows):
     """SURVEY.md §8(d) per-unit figures split per kernel; bytes for ONE launch over the batch."""
     P = sum(px)
-    if kernel in ("k_fast_cells", "k_fast_score+nms"):
+    if kernel in ("k_fast_cells", "k_fast_score+nms", "k_fast"):
         return B * P                                   # every pyramid pixel read once
     if kernel == "k_blur":
         return B * 2 * P                               # read level, write blurred level
@@ -47,7 +47,7 @@ def algorithmic_bytes(kernel, B, px, nkp_total, pairs_rows):
         return nkp_total * (600 + 512 + 60)            # IC patch + rBRIEF samples read, keypoint+descriptor written
     if kernel in ("k_copy_gray", "k_rgb2gray"):
         return B * 2 * px[0]
-    if kernel == "k_compact":
+    if kernel in ("k_compact", "k_quadtree"):
         return nkp_total * 8 * 6                       # ~6 candidates per kept keypoint, read + write 4 B
     if kernel == "k_hamming_knn2":
         return sum(32 * (nq + nt) + 16 * nq for nq, nt in pairs_rows)

@@ -149,11 +149,17 @@ struct ssvio_orb {
     size_t inBytes = 0;
     uint8_t* d_in = nullptr; uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; uint8_t* d_score = nullptr;
     int16_t* d_tabs = nullptr; std::vector<size_t> xTabOff, yTabOff, qTabOff; std::vector<char> quadOk; std::vector<int> resizeRows;
-    uint32_t* d_slots = nullptr; int* d_cellCount = nullptr;
-    uint32_t* d_cand = nullptr; int* d_candCount = nullptr;
-    uint2* d_kpIn = nullptr; int* d_kpCount = nullptr;
+    uint2* d_raw = nullptr; int* d_rawCount = nullptr; int* d_cellIni = nullptr;     // FAST output: unordered candidate lists
+    uint32_t* d_kval = nullptr; uint32_t* d_kord = nullptr; uint32_t* d_knode = nullptr;   // quadtree per-key scratch
+    uint2* d_sel = nullptr; int* d_selCount = nullptr;                                  // selected keypoints per level
+    int* d_kpCount = nullptr;
     ssvio_keypoint* d_kpOut = nullptr; uint8_t* d_desc = nullptr;
-    uint32_t* h_cand = nullptr; int* h_candCount = nullptr; uint2* h_kpIn = nullptr; int* h_kpCount = nullptr;
+    int* h_kpCount = nullptr;
+    bool hostQuadtree = false;     // SSVIO_QUADTREE=host, or a level quota beyond the GPU kernel's LDS capacity
+    int maxAlive = 0;
+    // host copies for the host quadtree mode and the debug taps (lazily sized)
+    std::vector<uint2> h_raw; std::vector<int> h_rawCount, h_cellIni; std::vector<uint2> h_sel; std::vector<int> h_selCount;
+    bool hostRawValid = false;
     KernelProfiler prof;
     std::unique_ptr<WorkerPool> pool;
     int lastBatch = 0;
@@ -162,9 +168,10 @@ struct ssvio_orb {
 
 static void orb_free_buffers(ssvio_orb* h)
 {
-    dfree(h->d_in); dfree(h->d_pyr); dfree(h->d_blur); dfree(h->d_score); dfree(h->d_tabs); dfree(h->d_slots); dfree(h->d_cellCount);
-    dfree(h->d_cand); dfree(h->d_candCount); dfree(h->d_kpIn); dfree(h->d_kpCount); dfree(h->d_kpOut); dfree(h->d_desc);
-    hfree(h->h_cand); hfree(h->h_candCount); hfree(h->h_kpIn); hfree(h->h_kpCount);
+    dfree(h->d_in); dfree(h->d_pyr); dfree(h->d_blur); dfree(h->d_tabs);
+    dfree(h->d_raw); dfree(h->d_rawCount); dfree(h->d_cellIni); dfree(h->d_kval); dfree(h->d_kord); dfree(h->d_knode);
+    dfree(h->d_sel); dfree(h->d_selCount); dfree(h->d_kpCount); dfree(h->d_kpOut); dfree(h->d_desc);
+    hfree(h->h_kpCount);
     h->batchCap = 0; h->inBytes = 0; h->haveResults = false;
 }
 
@@ -174,16 +181,19 @@ static void fill_klevels(const PyramidGeom& g, KLevels& k)
     k.nlevels = g.nlevels;
     for (int l = 0; l < g.nlevels; ++l) {
         const LevelGeom& L = g.lv[l];
-        k.w[l] = L.w; k.h[l] = L.h; k.pitch[l] = L.pitch; k.offset[l] = L.offset;
-        k.nCols[l] = L.nCols; k.nRows[l] = L.nRows; k.wCell[l] = L.wCell; k.hCell[l] = L.hCell;
-        k.cellBase[l] = L.cellBase; k.slotCap[l] = L.slotCap; k.slotBase[l] = L.slotBase;
-        k.fastTileBase[l] = L.fastTileBase; k.fastTilesX[l] = L.fastTilesX;
-        k.blurStripBase[l] = L.blurStripBase; k.blurStripsX[l] = L.blurStripsX; k.blurIters[l] = L.blurIters;
-        k.scale[l] = L.scale; k.kpSize[l] = L.kpSize;
+        KLevel& K = k.lv[l];
+        K.w = L.w; K.h = L.h; K.pitch = L.pitch; K.offset = L.offset;
+        K.nCols = L.nCols; K.nRows = L.nRows; K.wCell = L.wCell; K.hCell = L.hCell; K.cellBase = L.cellBase;
+        K.fastTileBase = L.fastTileBase; K.fastTilesX = L.fastTilesX;
+        K.blurStripBase = L.blurStripBase; K.blurStripsX = L.blurStripsX; K.blurIters = L.blurIters;
+        K.quota = L.quota; K.kpSize = L.kpSize; K.scale = L.scale;
+        K.rawBase = (unsigned)L.slotBase; K.rawCap = (unsigned)L.slotCap * L.nCols * L.nRows;
+        K.selBase = L.selBase; K.nIni = L.nIni; K.hX = L.hX;
+        for (int i = 0; i < 5; ++i) K.rootX[i] = L.rootX[i];
     }
-    k.cellBase[g.nlevels] = g.cellsPerFrame;
-    k.blurStripBase[g.nlevels] = g.blurStripsPerFrame;
-    k.fastTileBase[g.nlevels] = g.fastTilesPerFrame;
+    KLevel& E = k.lv[g.nlevels];
+    E.cellBase = g.cellsPerFrame; E.fastTileBase = g.fastTilesPerFrame; E.blurStripBase = g.blurStripsPerFrame;
+    E.rawBase = (unsigned)g.slotsPerFrame;
 }
 
 // (re)allocate for a w x h x batch configuration
@@ -222,23 +232,24 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
         const PyramidGeom& g = h->geom;
         const size_t B = (size_t)batch;
         h->kpCap = g.maxQuotaSum + 4 * g.nlevels;
-        if (h->candCap == 0) h->candCap = std::max(8192, 8 * h->tab.nfeatures);
+        h->maxAlive = 0;
+        for (int l = 0; l < g.nlevels; ++l) h->maxAlive = std::max(h->maxAlive, std::max(g.lv[l].quota + 3, 4 * g.lv[l].nIni));
+        if (h->maxAlive > 2048) h->hostQuadtree = true;           // beyond the LDS capacity of k_quadtree
         SSVIO_HIP(hipMalloc(&h->d_pyr, B * g.frameBytes));
         SSVIO_HIP(hipMalloc(&h->d_blur, B * g.frameBytes));
-        SSVIO_HIP(hipMalloc(&h->d_score, B * g.frameBytes));
         SSVIO_HIP(hipMemsetAsync(h->d_pyr, 0, B * g.frameBytes, h->stream));
         SSVIO_HIP(hipMemsetAsync(h->d_blur, 0, B * g.frameBytes, h->stream));
-        SSVIO_HIP(hipMalloc(&h->d_slots, B * g.slotsPerFrame * sizeof(uint32_t)));
-        SSVIO_HIP(hipMalloc(&h->d_cellCount, B * g.cellsPerFrame * sizeof(int)));
-        SSVIO_HIP(hipMalloc(&h->d_cand, B * h->candCap * sizeof(uint32_t)));
-        SSVIO_HIP(hipMalloc(&h->d_candCount, B * (kMaxLevels + 1) * sizeof(int)));
-        SSVIO_HIP(hipMalloc(&h->d_kpIn, B * h->kpCap * sizeof(uint2)));
+        SSVIO_HIP(hipMalloc(&h->d_raw, B * g.slotsPerFrame * sizeof(uint2)));
+        SSVIO_HIP(hipMalloc(&h->d_rawCount, B * kMaxLevels * sizeof(int)));
+        SSVIO_HIP(hipMalloc(&h->d_cellIni, B * g.cellsPerFrame * sizeof(int)));
+        SSVIO_HIP(hipMalloc(&h->d_kval, B * g.slotsPerFrame * sizeof(uint32_t)));
+        SSVIO_HIP(hipMalloc(&h->d_kord, B * g.slotsPerFrame * sizeof(uint32_t)));
+        SSVIO_HIP(hipMalloc(&h->d_knode, B * g.slotsPerFrame * sizeof(uint32_t)));
+        SSVIO_HIP(hipMalloc(&h->d_sel, B * h->kpCap * sizeof(uint2)));
+        SSVIO_HIP(hipMalloc(&h->d_selCount, B * kMaxLevels * sizeof(int)));
         SSVIO_HIP(hipMalloc(&h->d_kpCount, B * sizeof(int)));
         SSVIO_HIP(hipMalloc(&h->d_kpOut, B * h->kpCap * sizeof(ssvio_keypoint)));
         SSVIO_HIP(hipMalloc(&h->d_desc, B * h->kpCap * 32));
-        SSVIO_HIP(hipHostMalloc(&h->h_cand, B * h->candCap * sizeof(uint32_t), hipHostMallocDefault));
-        SSVIO_HIP(hipHostMalloc(&h->h_candCount, B * (kMaxLevels + 1) * sizeof(int), hipHostMallocDefault));
-        SSVIO_HIP(hipHostMalloc(&h->h_kpIn, B * h->kpCap * sizeof(uint2), hipHostMallocDefault));
         SSVIO_HIP(hipHostMalloc(&h->h_kpCount, B * sizeof(int), hipHostMallocDefault));
         h->batchCap = batch;
     }
@@ -251,93 +262,122 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
     return SSVIO_OK;
 }
 
-// grow the per-frame candidate capacity (rare: very dense frames)
-static int orb_grow_cand(ssvio_orb* h, int need)
+// copy the raw candidate lists of the last run to the host (host quadtree mode, debug taps)
+static int orb_fetch_raw(ssvio_orb* h, int batch)
 {
+    if (h->hostRawValid) return SSVIO_OK;
+    const PyramidGeom& g = h->geom;
+    h->h_rawCount.resize((size_t)batch * kMaxLevels); h->h_cellIni.resize((size_t)batch * g.cellsPerFrame);
+    h->h_raw.resize((size_t)batch * g.slotsPerFrame);
+    SSVIO_HIP(hipMemcpyAsync(h->h_rawCount.data(), h->d_rawCount, h->h_rawCount.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SSVIO_HIP(hipMemcpyAsync(h->h_cellIni.data(), h->d_cellIni, h->h_cellIni.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     SSVIO_HIP(hipStreamSynchronize(h->stream));
-    dfree(h->d_cand); hfree(h->h_cand);
-    h->candCap = need + need / 2;
-    SSVIO_HIP(hipMalloc(&h->d_cand, (size_t)h->batchCap * h->candCap * sizeof(uint32_t)));
-    SSVIO_HIP(hipHostMalloc(&h->h_cand, (size_t)h->batchCap * h->candCap * sizeof(uint32_t), hipHostMallocDefault));
+    for (int f = 0; f < batch; ++f)
+        for (int l = 0; l < g.nlevels; ++l) {
+            const int n = h->h_rawCount[(size_t)f * kMaxLevels + l];
+            if (n > 0) SSVIO_HIP(hipMemcpyAsync(h->h_raw.data() + (size_t)f * g.slotsPerFrame + g.lv[l].slotBase,
+                                                h->d_raw + (size_t)f * g.slotsPerFrame + g.lv[l].slotBase, (size_t)n * sizeof(uint2),
+                                                hipMemcpyDeviceToHost, h->stream));
+        }
+    SSVIO_HIP(hipStreamSynchronize(h->stream));
+    h->hostRawValid = true;
     return SSVIO_OK;
 }
 
-// the whole pipeline for `batch` frames whose level-0 images are already in d_pyr
+// candidates of (frame, level) in the reference's append order: resolve the per-cell 20->7 fallback, sort by key
+static void orb_host_candidates(ssvio_orb* h, int f, int l, std::vector<uint32_t>& vals)
+{
+    const PyramidGeom& g = h->geom;
+    const int n = h->h_rawCount[(size_t)f * kMaxLevels + l];
+    const uint2* r = h->h_raw.data() + (size_t)f * g.slotsPerFrame + g.lv[l].slotBase;
+    const int* ini = h->h_cellIni.data() + (size_t)f * g.cellsPerFrame + g.lv[l].cellBase;
+    std::vector<std::pair<uint32_t, uint32_t>> kv;
+    for (int i = 0; i < n; ++i) {
+        const int cell = (r[i].x >> 12) & 0x3FFFF, flags = r[i].x >> 30;
+        if (ini[cell] ? (flags & 1) : (flags & 2)) kv.emplace_back(r[i].x & 0x3FFFFFFFu, r[i].y);
+    }
+    std::sort(kv.begin(), kv.end());
+    vals.resize(kv.size());
+    for (size_t i = 0; i < kv.size(); ++i) vals[i] = kv[i].second;
+}
+
+// host quadtree mode: DistributeOctTree per (frame, level) on the worker pool, src/Feature.cpp:897-909
+static int orb_host_quadtree(ssvio_orb* h, int batch)
+{
+    const PyramidGeom& g = h->geom;
+    const int L = g.nlevels;
+    int rc = orb_fetch_raw(h, batch);
+    if (rc) return rc;
+    h->h_sel.assign((size_t)batch * h->kpCap, make_uint2(0, 0));
+    h->h_selCount.assign((size_t)batch * kMaxLevels, 0);
+    std::atomic<int> fail{0};
+    auto job = [&](int j) {
+        const int f = j / L, l = j % L;
+        std::vector<uint32_t> c;
+        orb_host_candidates(h, f, l, c);
+        const int n = (int)c.size();
+        if (n == 0) return;
+        std::vector<float> xs(n), ys(n), rs(n);
+        for (int i = 0; i < n; ++i) { xs[i] = (float)(c[i] & 0xFFF); ys[i] = (float)((c[i] >> 12) & 0xFFF); rs[i] = (float)(c[i] >> 24); }
+        const LevelGeom& G = g.lv[l];
+        std::vector<int> sel;
+        if (distribute_octtree(xs.data(), ys.data(), rs.data(), n, kMinBorder, G.maxBX, kMinBorder, G.maxBY, G.quota, sel)) { fail.store(1); return; }
+        if ((int)sel.size() > G.quota + 4) { fail.store(2); return; }
+        uint2* out = h->h_sel.data() + (size_t)f * h->kpCap + G.selBase;
+        for (size_t i = 0; i < sel.size(); ++i) {
+            const uint32_t e = c[sel[i]];
+            const uint32_t x = (e & 0xFFF) + kMinBorder, y = ((e >> 12) & 0xFFF) + kMinBorder;   // src/Feature.cpp:905-906
+            out[i] = make_uint2(x | (y << 16), (uint32_t)l | ((e >> 24) << 8));
+        }
+        h->h_selCount[(size_t)f * kMaxLevels + l] = (int)sel.size();
+    };
+    h->pool->run(batch * L, job);
+    if (fail.load()) { set_error("host quadtree failed (%d)", fail.load()); return SSVIO_ERR_GEOMETRY; }
+    SSVIO_HIP(hipMemcpyAsync(h->d_sel, h->h_sel.data(), h->h_sel.size() * sizeof(uint2), hipMemcpyHostToDevice, h->stream));
+    SSVIO_HIP(hipMemcpyAsync(h->d_selCount, h->h_selCount.data(), h->h_selCount.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    return SSVIO_OK;
+}
+
+// the whole pipeline for `batch` frames whose level-0 images are already in d_pyr; everything is
+// enqueued on the stream, the host only waits for the per-frame keypoint counts at the end
 static int orb_run(ssvio_orb* h, int batch)
 {
     const PyramidGeom& g = h->geom;
     hipStream_t s = h->stream;
+    h->hostRawValid = false;
+    SSVIO_HIP(hipMemsetAsync(h->d_rawCount, 0, (size_t)batch * kMaxLevels * sizeof(int), s));
+    SSVIO_HIP(hipMemsetAsync(h->d_cellIni, 0, (size_t)batch * g.cellsPerFrame * sizeof(int), s));
     for (int l = 1; l < g.nlevels; ++l) {
         ProfScope p(h->prof, "k_resize", s);
         launch_resize(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], h->qTabOff[l], (int)h->quadOk[l], h->resizeRows[l], batch, s);
     }
     {
-        ProfScope p(h->prof, "k_fast_score+nms", s);
-        launch_fast(h->d_pyr, h->d_score, g.frameBytes, h->kl, g.fastTilesPerFrame, g.cellsPerFrame, g.slotsPerFrame,
-                    h->tab.iniTh, h->tab.minTh, h->d_slots, h->d_cellCount, batch, s);
+        ProfScope p(h->prof, "k_fast", s);
+        launch_fast(h->d_pyr, g.frameBytes, h->kl, g.fastTilesPerFrame, g.cellsPerFrame, g.slotsPerFrame, h->tab.iniTh, h->tab.minTh,
+                    h->d_raw, h->d_rawCount, h->d_cellIni, batch, s);
     }
-    for (int attempt = 0;; ++attempt) {
-        {
-            ProfScope p(h->prof, "k_compact", s);
-            launch_compact(h->kl, g.cellsPerFrame, g.slotsPerFrame, h->d_slots, h->d_cellCount, h->d_cand, h->candCap, h->d_candCount, batch, s);
-        }
-        SSVIO_HIP(hipMemcpyAsync(h->h_candCount, h->d_candCount, (size_t)batch * (kMaxLevels + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(h->h_cand, h->d_cand, (size_t)batch * h->candCap * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipEventRecord(h->evCand, s));
-        if (attempt == 0) {
-            // the blur does not depend on the keypoints: it runs while the host distributes them
-            ProfScope p(h->prof, "k_blur", s);
-            launch_blur(h->d_pyr, h->d_blur, g.frameBytes, h->kl, g.blurStripsPerFrame, batch, s);
-        }
-        SSVIO_HIP(hipEventSynchronize(h->evCand));
-        int need = 0;
-        for (int f = 0; f < batch; ++f) need = std::max(need, h->h_candCount[f * (kMaxLevels + 1) + kMaxLevels]);
-        if (need <= h->candCap) break;
-        if (attempt >= 2) { set_error("internal: candidate buffer growth failed"); return SSVIO_ERR_HIP; }
-        const int rc = orb_grow_cand(h, need);
-        if (rc) return rc;
+    if (!h->hostQuadtree) {
+        QtArgs a{};
+        a.kl = h->kl; a.raw = h->d_raw; a.rawCount = h->d_rawCount; a.cellIni = h->d_cellIni;
+        a.rawPerFrame = g.slotsPerFrame; a.cellsPerFrame = g.cellsPerFrame;
+        a.kval = h->d_kval; a.kord = h->d_kord; a.knode = h->d_knode;
+        a.sel = h->d_sel; a.selCount = h->d_selCount; a.selPerFrame = h->kpCap;
+        ProfScope p(h->prof, "k_quadtree", s);
+        if (launch_quadtree(a, h->maxAlive, g.nlevels, batch, s)) { set_error("internal: quadtree capacity"); return SSVIO_ERR_INVALID; }
     }
-    // host stage: DistributeOctTree per (frame, level), src/Feature.cpp:897-909
-    const int L = g.nlevels;
-    std::vector<std::vector<int>> sel((size_t)batch * L);
-    std::atomic<int> fail{0};
-    auto job = [&](int j) {
-        const int f = j / L, l = j % L;
-        const int* cnt = h->h_candCount + f * (kMaxLevels + 1);
-        int off = 0;
-        for (int i = 0; i < l; ++i) off += cnt[i];
-        const int n = cnt[l];
-        const uint32_t* c = h->h_cand + (size_t)f * h->candCap + off;
-        std::vector<float> xs(n), ys(n), rs(n);
-        for (int i = 0; i < n; ++i) { xs[i] = (float)(c[i] & 0xFFF); ys[i] = (float)((c[i] >> 12) & 0xFFF); rs[i] = (float)(c[i] >> 24); }
-        const LevelGeom& G = g.lv[l];
-        if (n == 0) { sel[j].clear(); return; }
-        if (distribute_octtree(xs.data(), ys.data(), rs.data(), n, kMinBorder, G.maxBX, kMinBorder, G.maxBY, G.quota, sel[j])) fail.store(1);
-    };
-    h->pool->run(batch * L, job);
-    if (fail.load()) return SSVIO_ERR_GEOMETRY;
-    for (int f = 0; f < batch; ++f) {
-        const int* cnt = h->h_candCount + f * (kMaxLevels + 1);
-        uint2* kp = h->h_kpIn + (size_t)f * h->kpCap;
-        int n = 0, off = 0;
-        for (int l = 0; l < L; ++l) {
-            const uint32_t* c = h->h_cand + (size_t)f * h->candCap + off;
-            for (int idx : sel[(size_t)f * L + l]) {
-                if (n >= h->kpCap) { set_error("internal: keypoint capacity %d exceeded", h->kpCap); return SSVIO_ERR_CAPACITY; }
-                const uint32_t e = c[idx];
-                const uint32_t x = (e & 0xFFF) + kMinBorder, y = ((e >> 12) & 0xFFF) + kMinBorder;   // src/Feature.cpp:905-906
-                kp[n++] = make_uint2(x | (y << 16), (uint32_t)l | ((e >> 24) << 8));
-            }
-            off += cnt[l];
-        }
-        h->h_kpCount[f] = n;
+    {
+        // the blur does not depend on the keypoints
+        ProfScope p(h->prof, "k_blur", s);
+        launch_blur(h->d_pyr, h->d_blur, g.frameBytes, h->kl, g.blurStripsPerFrame, batch, s);
     }
-    SSVIO_HIP(hipMemcpyAsync(h->d_kpIn, h->h_kpIn, (size_t)batch * h->kpCap * sizeof(uint2), hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipMemcpyAsync(h->d_kpCount, h->h_kpCount, (size_t)batch * sizeof(int), hipMemcpyHostToDevice, s));
+    if (h->hostQuadtree) { const int rc = orb_host_quadtree(h, batch); if (rc) return rc; }
     {
         ProfScope p(h->prof, "k_describe", s);
-        launch_describe(h->d_pyr, h->d_blur, g.frameBytes, h->kl, h->d_kpIn, h->d_kpCount, h->kpCap, h->d_kpOut, h->d_desc, batch, s);
+        launch_describe(h->d_pyr, h->d_blur, g.frameBytes, h->kl, h->d_sel, h->d_selCount, h->kpCap, h->kpCap, h->d_kpOut, h->d_desc,
+                        h->d_kpCount, batch, s);
     }
+    SSVIO_HIP(hipMemcpyAsync(h->h_kpCount, h->d_kpCount, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
     h->lastBatch = batch; h->haveResults = true;
     return SSVIO_OK;
 }
@@ -374,6 +414,7 @@ int ssvio_orb_create(const ssvio_orb_params* params, int device, ssvio_orb** out
     }
     h->stream = h->own;
     h->pool.reset(new WorkerPool(host_threads() - 1));
+    if (const char* e = std::getenv("SSVIO_QUADTREE")) h->hostQuadtree = std::string(e) == "host";
     *out = h;
     return SSVIO_OK;
 }
@@ -569,13 +610,14 @@ int ssvio_orb_debug_candidates(ssvio_orb* h, int frame, int level, int32_t* xs, 
 {
     if (orb_check(h)) return SSVIO_ERR_INVALID;
     if (!h->haveResults || frame < 0 || frame >= h->lastBatch || level < 0 || level >= h->geom.nlevels || !n) { set_error("bad frame/level or no results"); return SSVIO_ERR_INVALID; }
-    const int* cnt = h->h_candCount + frame * (kMaxLevels + 1);
-    int off = 0;
-    for (int i = 0; i < level; ++i) off += cnt[i];
-    const int c = cnt[level];
+    SSVIO_HIP(hipSetDevice(h->device));
+    const int rc = orb_fetch_raw(h, h->lastBatch);
+    if (rc) return rc;
+    std::vector<uint32_t> e;
+    orb_host_candidates(h, frame, level, e);
+    const int c = (int)e.size();
     *n = c;
     if (c > cap) { set_error("capacity %d < %d candidates", cap, c); return SSVIO_ERR_CAPACITY; }
-    const uint32_t* e = h->h_cand + (size_t)frame * h->candCap + off;
     for (int i = 0; i < c; ++i) { if (xs) xs[i] = e[i] & 0xFFF; if (ys) ys[i] = (e[i] >> 12) & 0xFFF; if (resp) resp[i] = e[i] >> 24; }
     return SSVIO_OK;
 }

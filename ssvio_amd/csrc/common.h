@@ -35,7 +35,9 @@ struct LevelGeom {
     int maxBX, maxBY;         // w-16, h-16
     int cellBase;             // first cell index of this level within a frame
     int slotCap;              // worst-case keypoints per cell after NMS
-    size_t slotBase;          // first slot entry of this level within a frame
+    size_t slotBase;          // first raw-list entry of this level within a frame (= sum of cells * slotCap)
+    int selBase;              // first selected-keypoint entry of this level within a frame
+    int nIni; float hX; int rootX[5];   // quadtree roots
     int quota;                // mnFeaturesPerLevel
     float scale;              // mvScaleFactor
     int kpSize;               // (int)(15*scale)
@@ -56,19 +58,35 @@ struct PyramidGeom {
     int maxQuotaSum = 0;
 };
 
-// parameters handed to kernels by value
+// parameters handed to kernels by value: one record per level (a wave-uniform level index turns
+// into a handful of scalar loads), plus a sentinel record whose *Base fields hold the totals
+struct KLevel {
+    int w, h, pitch;
+    int nCols, nRows, wCell, hCell;
+    int cellBase;
+    int fastTileBase, fastTilesX;
+    int blurStripBase, blurStripsX, blurIters;
+    int quota, kpSize;
+    float scale;
+    unsigned long long offset;        // byte offset of pixel (0,0) inside a frame's pyramid
+    unsigned int rawBase, rawCap;     // this level's region of the raw candidate list of a frame (entries)
+    int selBase;                      // this level's region of the selected-keypoint list of a frame
+    int nIni; float hX; int rootX[5]; // quadtree roots (src/Feature.cpp:574-593)
+    int pad0;
+};
 struct KLevels {
     int nlevels;
-    int w[kMaxLevels], h[kMaxLevels], pitch[kMaxLevels];
-    unsigned long long offset[kMaxLevels];
-    int nCols[kMaxLevels], nRows[kMaxLevels], wCell[kMaxLevels], hCell[kMaxLevels];
-    int cellBase[kMaxLevels + 1];
-    int slotCap[kMaxLevels];
-    unsigned long long slotBase[kMaxLevels];
-    int blurStripBase[kMaxLevels + 1], blurStripsX[kMaxLevels], blurIters[kMaxLevels];
-    int fastTileBase[kMaxLevels + 1], fastTilesX[kMaxLevels];
-    float scale[kMaxLevels];
-    int kpSize[kMaxLevels];
+    int pad[3];
+    KLevel lv[kMaxLevels + 1];
+};
+
+// arguments of the quadtree kernel
+struct QtArgs {
+    KLevels kl;
+    const uint2* raw; const int* rawCount; const int* cellIni;
+    size_t rawPerFrame; int cellsPerFrame;
+    uint32_t* kval; uint32_t* kord; uint32_t* knode;     // per-key scratch, same indexing as raw
+    uint2* sel; int* selCount; int selPerFrame;
 };
 
 struct ExtractorTables {
@@ -121,13 +139,15 @@ void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frame
                       uint8_t* pyr, size_t pyrFrameBytes, int pitch0, hipStream_t s);
 void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int level, const int16_t* tabs,
                    size_t xTabOff, size_t yTabOff, size_t quadTabOff, int mode /*0 generic, 1 quad, 2 area 2x2*/, int rows, int batch, hipStream_t s);
-void launch_fast(const uint8_t* pyr, uint8_t* score, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, int cellsPerFrame,
-                 size_t slotsPerFrame, int iniTh, int minTh, uint32_t* slots, int* cellCount, int batch, hipStream_t s);
-void launch_compact(const KLevels& kl, int cellsPerFrame, size_t slotsPerFrame, const uint32_t* slots, const int* cellCount,
-                    uint32_t* cand, int candCap, int* candCount /*[batch][kMaxLevels+1]*/, int batch, hipStream_t s);
+// FAST: appends {key, val} per NMS survivor to the level's raw list; key = flags<<30 | cell<<12 | iy<<6 | ix
+// (flags bit0: passes at iniTh, bit1: at minTh), val = x | y<<12 | score<<24 relative to minBorder
+void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, int cellsPerFrame, size_t rawPerFrame,
+                 int iniTh, int minTh, uint2* raw, int* rawCount, int* cellIni, int batch, hipStream_t s);
+int  launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipStream_t s);
 void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int stripsPerFrame, int batch, hipStream_t s);
-// kpIn: per keypoint {x | y<<16, level | resp<<8}; offsets per frame = f*cap
+// sel: per level lists {x | y<<16, level | resp<<8} at f*selPerFrame + selBase[l]; selCount[f][kMaxLevels]
 void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl,
-                     const uint2* kpIn, const int* kpCount, int cap, ssvio_keypoint* kpOut, uint8_t* desc, int batch, hipStream_t s);
+                     const uint2* sel, const int* selCount, int selPerFrame, int cap, ssvio_keypoint* kpOut, uint8_t* desc,
+                     int* kpCount, int batch, hipStream_t s);
 
 }  // namespace ssvio

@@ -76,6 +76,7 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
         }
         L.wCell = (int)std::ceil(fw / L.nCols); L.hCell = (int)std::ceil(fh / L.nRows);
         const int nIni = (int)std::round(fw / fh);                    // src/Feature.cpp:574
+        if (nIni > 4) { set_error("level %d aspect ratio %g needs %d quadtree roots (max 4 supported)", l, fw / fh, nIni); return SSVIO_ERR_GEOMETRY; }
         if (nIni < 1) { set_error("level %d aspect ratio %g rounds to zero quadtree roots (src/Feature.cpp:574)", l, fw / fh); return SSVIO_ERR_GEOMETRY; }
         if (L.wCell > kMaxCellDim || L.hCell > kMaxCellDim) { set_error("internal: cell %dx%d exceeds %d", L.wCell, L.hCell, kMaxCellDim); return SSVIO_ERR_GEOMETRY; }
         L.pitch = ((L.w + 63) / 64) * 64 + 128;         // 64-B aligned rows, 64 B of slack on both sides (pad columns, vector reads)
@@ -85,6 +86,9 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
         L.cellBase = cell; cell += L.nCols * L.nRows;
         L.slotCap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);        // NMS leaves no two 8-adjacent maxima
         L.slotBase = slot; slot += (size_t)L.slotCap * L.nCols * L.nRows;
+        L.selBase = g.maxQuotaSum + 4 * l;
+        L.nIni = nIni; L.hX = fw / nIni;                                 // :576
+        for (int i = 0; i <= nIni; ++i) L.rootX[i] = (int)(L.hX * (float)i);   // :585-586
         L.quota = t.quota[l]; L.scale = t.scale[l]; L.kpSize = (int)(kHalfPatch * t.scale[l]);   // src/Feature.cpp:900
         // k_blur strips: 120 output px wide (32 lanes x 4 px, first/last lane are halo), 7*iters-6 rows tall
         L.blurStripsX = (L.w + 119) / 120;

@@ -165,38 +165,40 @@ __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, 
 void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int level, const int16_t* tabs,
                    size_t xTabOff, size_t yTabOff, size_t quadTabOff, int mode, int rows, int batch, hipStream_t s)
 {
-    const int dw = kl.w[level], dh = kl.h[level];
+    const int dw = kl.lv[level].w, dh = kl.lv[level].h;
     if (mode == 1) {
         const int nq = (dw + 2 * kPadX + 3) / 4;
         dim3 grid((nq + 63) / 64, (dh + 4 * rows - 1) / (4 * rows), batch);
         hipLaunchKernelGGL(k_resize_quad, grid, dim3(256), 0, s, pyr, pyrFrameBytes,
-                           kl.offset[level - 1], kl.pitch[level - 1], kl.offset[level], kl.pitch[level], nq, dh, rows,
+                           kl.lv[level - 1].offset, kl.lv[level - 1].pitch, kl.lv[level].offset, kl.lv[level].pitch, nq, dh, rows,
                            (const ResizeQuad*)(tabs + quadTabOff), (const short4*)(tabs + yTabOff));
         return;
     }
     dim3 grid((dw + 2 * kPadX + 255) / 256, (dh + 3) / 4, batch);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, pyr, pyrFrameBytes,
-                       kl.offset[level - 1], kl.pitch[level - 1], kl.offset[level], kl.pitch[level], dw, dh,
+                       kl.lv[level - 1].offset, kl.lv[level - 1].pitch, kl.lv[level].offset, kl.lv[level].pitch, dw, dh,
                        (const short4*)(tabs + xTabOff), (const short4*)(tabs + yTabOff), mode == 2 ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------
-// FAST-9/16 (src/Feature.cpp:851-892 with cv::FAST per SURVEY App. A3) in two kernels.
+// FAST-9/16 + score + cell-local NMS + ini/min threshold flags (src/Feature.cpp:851-892 with
+// cv::FAST per SURVEY App. A3), one kernel, 64x32-pixel tiles.
 //
-// cv::FAST's score of a corner is  s = max(maxmin_dark, maxmin_bright) - 1  where
-// maxmin_dark = max over the 16 arcs of 9 ring pixels of min(v - ring); it does not depend on the
-// threshold, and pixel p is a corner at threshold T  <=>  s(p) >= T.  The score of a pixel only
-// needs its own radius-3 ring, which always lies inside the window of the cell that tests the
-// pixel, so the score map is independent of the 30-px cell grid:
-//   k_fast_score  dense score map of a level (0 where s < min(iniTh,minTh) or outside the tested
-//                 region [19, w-20] x [19, h-20]), 64x32-pixel tiles;
-//   k_fast_nms    per cell: M_T(q) = s(q) >= T ? s(q) : 0 restricted to the cell's tested interior
-//                 (everything else counts as 0, as cv::FAST's untested rim does), keep p iff
-//                 s(p) >= T and s(p) > M_T(q) for its 8 neighbours; T = iniTh, or minTh when the
-//                 iniTh list of the cell is empty (:875); emit in raster order.
-constexpr int kFtW = 64, kFtH = 32;          // output tile of k_fast_score
-constexpr int kFtPitch = 72;                 // LDS row: x0-4 .. x0+67
-constexpr int kFtRows = kFtH + 6;
+// cv::FAST's score of a corner is  s = max(maxmin_dark, maxmin_bright) - 1  where maxmin_dark =
+// max over the 16 arcs of 9 ring pixels of min(v - ring); it does not depend on the threshold, and
+// pixel p is a corner at threshold T  <=>  s(p) >= T.  The score only needs the pixel's own radius-3
+// ring, which always lies inside the window of the 30-px cell that tests the pixel, so scores are
+// computed densely (tile + 1-px halo) and only the NMS looks at the cell grid: with
+// M_T(q) = s(q) >= T ? s(q) : 0 for q in the SAME cell's tested interior (0 elsewhere, as cv::FAST's
+// untested rim), p is kept at T iff s(p) >= T and s(p) > max_q M_T(q) over its 8 neighbours; since
+// thresholding is monotone, max_q M_T(q) = M_T(max_q s(q)).
+// Survivors are appended (unordered) to the level's raw list with both flags (iniTh / minTh) and their
+// position in the reference's append order as key; cellIni[cell] is raised when a cell has an iniTh
+// survivor, which is what decides the minTh retry of src/Feature.cpp:875 (resolved by the consumer).
+constexpr int kFtW = 64, kFtH = 32;          // output tile
+constexpr int kFtPitch = 72;                 // LDS row bytes: x0-4 .. x0+67
+constexpr int kFtRows = kFtH + 8;            // input rows y0-4 .. y0+35
+constexpr int kScRows = kFtH + 2;            // score rows y0-1 .. y0+32 (same column layout as the input tile)
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 
@@ -217,21 +219,32 @@ __device__ __forceinline__ short2v arc9_maxmin_pk(const short2v (&p)[16])
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
-                                                    size_t pyrFrameBytes, KLevels kl, int tLow)
+__device__ __forceinline__ int find_fast_level(const KLevels& kl, int id)
+{
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; ++l) level += (l < kl.nlevels && id >= kl.lv[l].fastTileBase) ? 1 : 0;
+    return level;
+}
+
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, size_t pyrFrameBytes, KLevels kl, int cellsPerFrame,
+                                              size_t rawPerFrame, int iniTh, int minTh, uint2* __restrict__ raw,
+                                              int* __restrict__ rawCount, int* __restrict__ cellIni)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kFtRows * kFtPitch / 4];
-    __shared__ __attribute__((aligned(16))) uint32_t sc[kFtW * kFtH / 4];
-    __shared__ uint16_t queue[kFtW * kFtH];
-    __shared__ int qn;
+    __shared__ __attribute__((aligned(16))) uint32_t sc[kScRows * kFtPitch / 4];
+    __shared__ uint16_t queue[kScRows * kFtPitch];
+    __shared__ uint2 outbuf[kFtW * kFtH / 4];            // NMS survivors of one tile: no two are 8-adjacent within a cell
+    __shared__ int qn, on, obase;
     const int tid = threadIdx.x, frame = blockIdx.y;
-    int level = 0;
-    while (level + 1 < kl.nlevels && (int)blockIdx.x >= kl.fastTileBase[level + 1]) ++level;
-    const int t = blockIdx.x - kl.fastTileBase[level];
-    const int tyi = t / kl.fastTilesX[level], txi = t - tyi * kl.fastTilesX[level];
-    const int w = kl.w[level], h = kl.h[level], pitch = kl.pitch[level];
+    const int level = find_fast_level(kl, blockIdx.x);
+    const KLevel& L = kl.lv[level];
+    const int t = blockIdx.x - L.fastTileBase;
+    const int tyi = t / L.fastTilesX, txi = t - tyi * L.fastTilesX;
+    const int w = L.w, h = L.h, pitch = L.pitch;
     const int x0 = txi * kFtW, y0 = tyi * kFtH;
-    const uint8_t* img = pyr + (size_t)frame * pyrFrameBytes + kl.offset[level];
+    const int tLow = min(iniTh, minTh);
+    const uint8_t* img = pyr + (size_t)frame * pyrFrameBytes + L.offset;
     const int xMaxLoad = (w + 56) & ~3;                    // last dword that is still inside the row's slack
     {
         uint32_t ld[3];
@@ -239,43 +252,49 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
         for (int k = 0; k < 3; ++k) {
             const int i = tid + k * 256;
             const int r = (i * 3641) >> 16, c = i - r * (kFtPitch / 4);        // i / 18 for i < 1100
-            const int yy = min(max(y0 - 3 + r, 0), h - 1);
+            const int yy = min(max(y0 - 4 + r, 0), h - 1);
             ld[k] = i < kFtRows * (kFtPitch / 4) ? *(const uint32_t*)(img + (size_t)yy * pitch + min(x0 - 4 + 4 * c, xMaxLoad)) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { const int i = tid + k * 256; if (i < kFtRows * (kFtPitch / 4)) tile[i] = ld[k]; }
     }
-    for (int i = tid; i < kFtW * kFtH / 4; i += 256) sc[i] = 0;
-    if (tid == 0) qn = 0;
+    for (int i = tid; i < kScRows * kFtPitch / 4; i += 256) sc[i] = 0;
+    if (tid == 0) { qn = 0; on = 0; }
     __syncthreads();
     const uint8_t* tb = (const uint8_t*)tile;
     // phase 1, packed: a 9-arc always contains two ADJACENT compass pixels (ring 0,4,8,12); "some adjacent
     // compass pair in one class" == (down|up) & (left|right) per class.  Two pixels per packed-i16 register:
     // darker-by-more-than-T mask = (T - (v - n)) >> 15, brighter mask = (T + (v - n)) >> 15.
+    // Domain: score rows y0-1 .. y0+32, quad columns x0-4 .. x0+67 (pixels outside x0-1 .. x0+64 are dropped).
     unsigned flags = 0;                                     // bit (4k+i): pixel i of this thread's quad k survives
     const short2v T2 = short2v{(short)tLow, (short)tLow};
+    constexpr int kQuads = kScRows * (kFtPitch / 4);        // 34 * 18 = 612
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int q = tid + k * 256, qc = q & 15, r = q >> 4;
-        const uint32_t C = tile[(r + 3) * (kFtPitch / 4) + qc + 1], L = tile[(r + 3) * (kFtPitch / 4) + qc],
-                       R = tile[(r + 3) * (kFtPitch / 4) + qc + 2];
-        const uint32_t U = tile[r * (kFtPitch / 4) + qc + 1], D = tile[(r + 6) * (kFtPitch / 4) + qc + 1];
-        const uint32_t lw = __builtin_amdgcn_alignbyte(C, L, 1);      // bytes x-3 .. x
-        const uint32_t rw = __builtin_amdgcn_alignbyte(R, C, 3);      // bytes x+3 .. x+6
-        const int y = y0 + r;
-        const bool rowOk = y >= kEdge && y <= h - kEdge - 1;
+    for (int k = 0; k < 3; ++k) {
+        const int q = tid + k * 256;
+        if (q < kQuads) {
+            const int r = (q * 3641) >> 16, qc = q - r * (kFtPitch / 4);
+            const int rowC = (r + 3) * (kFtPitch / 4);          // input row of score row r
+            const uint32_t C = tile[rowC + qc], Lf = qc > 0 ? tile[rowC + qc - 1] : 0u, Rt = qc < 17 ? tile[rowC + qc + 1] : 0u;
+            const uint32_t U = tile[rowC - 3 * (kFtPitch / 4) + qc], D = tile[rowC + 3 * (kFtPitch / 4) + qc];
+            const uint32_t lw = __builtin_amdgcn_alignbyte(C, Lf, 1);     // bytes x-3 .. x
+            const uint32_t rw = __builtin_amdgcn_alignbyte(Rt, C, 3);     // bytes x+3 .. x+6
+            const int y = y0 - 1 + r;
+            const bool rowOk = y >= kEdge && y <= h - kEdge - 1;
 #pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-            const uint32_t sel = hlf ? 0x0c030c02u : 0x0c010c00u;      // bytes (0,1) or (2,3) -> two u16
-            auto pk = [&](uint32_t x) { return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, x, sel)); };
-            const short2v v = pk(C);
-            const short2v du = v - pk(U), dd = v - pk(D), dl = v - pk(lw), dr = v - pk(rw);
-            const short2v darkV = ((T2 - du) >> 15) | ((T2 - dd) >> 15), darkH = ((T2 - dl) >> 15) | ((T2 - dr) >> 15);
-            const short2v brtV = ((T2 + du) >> 15) | ((T2 + dd) >> 15), brtH = ((T2 + dl) >> 15) | ((T2 + dr) >> 15);
-            const uint32_t m = __builtin_bit_cast(uint32_t, (short2v)((darkV & darkH) | (brtV & brtH)));
-            const int xa = x0 + 4 * qc + 2 * hlf;
-            if (rowOk && (m & 1u) && xa >= kEdge && xa <= w - kEdge - 1) flags |= 1u << (4 * k + 2 * hlf);
-            if (rowOk && (m & 0x10000u) && xa + 1 >= kEdge && xa + 1 <= w - kEdge - 1) flags |= 1u << (4 * k + 2 * hlf + 1);
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const uint32_t sel = hlf ? 0x0c030c02u : 0x0c010c00u;      // bytes (0,1) or (2,3) -> two u16
+                auto pk = [&](uint32_t x) { return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, x, sel)); };
+                const short2v v = pk(C);
+                const short2v du = v - pk(U), dd = v - pk(D), dl = v - pk(lw), dr = v - pk(rw);
+                const short2v darkV = ((T2 - du) >> 15) | ((T2 - dd) >> 15), darkH = ((T2 - dl) >> 15) | ((T2 - dr) >> 15);
+                const short2v brtV = ((T2 + du) >> 15) | ((T2 + dd) >> 15), brtH = ((T2 + dl) >> 15) | ((T2 + dr) >> 15);
+                const uint32_t m = __builtin_bit_cast(uint32_t, (short2v)((darkV & darkH) | (brtV & brtH)));
+                const int lx = 4 * qc + 2 * hlf - 4;             // tile-local x of the first of the two pixels
+                const int xa = x0 + lx;
+                if (rowOk && (m & 1u) && lx >= -1 && lx <= kFtW && xa >= kEdge && xa <= w - kEdge - 1) flags |= 1u << (4 * k + 2 * hlf);
+                if (rowOk && (m & 0x10000u) && lx + 1 >= -1 && lx + 1 <= kFtW && xa + 1 >= kEdge && xa + 1 <= w - kEdge - 1) flags |= 1u << (4 * k + 2 * hlf + 1);
+            }
         }
     }
     {   // one queue reservation per wave
@@ -285,15 +304,16 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o); if (lane >= o) incl += tt; }
         const int tot = __shfl(incl, 63);
-        int base = 0;
         if (tot) {
+            int base = 0;
             if (lane == 63) base = atomicAdd(&qn, tot);
             base = __shfl(base, 63) + incl - cnt;
             unsigned f = flags;
             while (f) {
                 const int bit = __ffs(f) - 1; f &= f - 1;
-                const int q = tid + (bit >> 2) * 256, qc = q & 15, r = q >> 4;
-                queue[base++] = (uint16_t)(r * kFtW + 4 * qc + (bit & 3));
+                const int q = tid + (bit >> 2) * 256;
+                const int r = (q * 3641) >> 16, qc = q - r * (kFtPitch / 4);
+                queue[base++] = (uint16_t)(r * kFtPitch + 4 * qc + (bit & 3));      // byte index into the score tile
             }
         }
     }
@@ -302,8 +322,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
     // phase 2: exact score of the queued pixels
     for (int q = tid; q < nq; q += 256) {
         const int p = queue[q];
-        const int ly = p >> 6, lx = p & 63;
-        const uint8_t* c = tb + (ly + 3) * kFtPitch + lx + 4;
+        const uint8_t* c = tb + p + 3 * kFtPitch;               // score row r <-> input row r + 3, same columns
         const int v = c[0];
         short2v d[16];
 #define RING(K, OFF) { const int dd = v - c[OFF]; d[K] = short2v{(short)dd, (short)-dd}; }
@@ -317,174 +336,54 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
         if (s >= tLow && s > 0) ((uint8_t*)sc)[p] = (uint8_t)s;
     }
     __syncthreads();
-    uint8_t* out = score + (size_t)frame * pyrFrameBytes + kl.offset[level];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int q = tid + k * 256, qc = q & 15, r = q >> 4;
-        if (y0 + r < h && x0 + 4 * qc < w + 4) *(uint32_t*)(out + (size_t)(y0 + r) * pitch + x0 + 4 * qc) = sc[q];
-    }
-}
-
-constexpr int kNmsPitch = 72;                // LDS bytes per staged score row (4 zero bytes + <= 17 dwords)
-constexpr int kNmsRows = kMaxCellDim + 2;
-
-__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ score, size_t pyrFrameBytes, KLevels kl,
-                                                  int cellsPerFrame, size_t slotsPerFrame, int iniTh, int minTh,
-                                                  uint32_t* __restrict__ slots, int* __restrict__ cellCount)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t stage[4][kNmsRows * kNmsPitch / 4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int frame = blockIdx.y;
-    const int cell = blockIdx.x * 4 + wv;
-    const bool have = cell < cellsPerFrame;
-    int level = 0;
-    while (level + 1 < kl.nlevels && cell >= kl.cellBase[level + 1]) ++level;
-    const int lc = have ? cell - kl.cellBase[level] : 0;
-    const int ci = lc / kl.nCols[level], cj = lc - ci * kl.nCols[level];
-    const int wCell = kl.wCell[level], hCell = kl.hCell[level];
-    const int maxBX = kl.w[level] - kMinBorder, maxBY = kl.h[level] - kMinBorder;
-    const int iniX = kMinBorder + cj * wCell, iniY = kMinBorder + ci * hCell;
-    // cells the reference skips (src/Feature.cpp:856, :866) have an empty tested interior anyway
-    const int iw = have ? max(min(iniX + wCell + 6, maxBX) - iniX - 6, 0) : 0;
-    const int ih = have ? max(min(iniY + hCell + 6, maxBY) - iniY - 6, 0) : 0;
-    const bool skip = !have || iniY >= maxBY - 3 || iniX >= maxBX - 6 || iw == 0 || ih == 0;
-    const int X0 = iniX + 3, Y0 = iniY + 3;                // first tested pixel
-    const int xa = X0 & ~3;                                // aligned start of the staged rows
-    const int nd = skip ? 0 : ((X0 + iw + 3) >> 2) - (xa >> 2);   // dwords per row (<= 17)
-    const int pitch = kl.pitch[level];
-    const uint8_t* src = score + (size_t)frame * pyrFrameBytes + kl.offset[level];
-    uint32_t* st = stage[wv];
-    uint8_t* sb = (uint8_t*)st;
-    // stage rows -1 .. ih (rows -1 and ih are zero), bytes outside [X0, X0+iw) zeroed; all of a lane's
-    // loads are issued before the first use (one round of memory latency per cell)
-    const int rowsStaged = skip ? 0 : ih + 2;
-    constexpr int kStageIters = (kNmsRows * (kNmsPitch / 4) + 63) / 64;
-    uint32_t sv[kStageIters];
-#pragma unroll
-    for (int k = 0; k < kStageIters; ++k) {
-        const int i = lane + 64 * k;
-        const int r = (i * 3641) >> 16, c = i - r * (kNmsPitch / 4);          // c = 0 is the zero dword left of xa
-        sv[k] = 0;
-        if (i < rowsStaged * (kNmsPitch / 4) && r >= 1 && r <= ih && c >= 1 && c <= nd)
-            sv[k] = *(const uint32_t*)(src + (size_t)(Y0 + r - 1) * pitch + xa + 4 * (c - 1));
-    }
-#pragma unroll
-    for (int k = 0; k < kStageIters; ++k) {
-        const int i = lane + 64 * k;
-        if (i < rowsStaged * (kNmsPitch / 4)) {
-            const int r = (i * 3641) >> 16, c = i - r * (kNmsPitch / 4);
-            const int xd = xa + 4 * (c - 1);
-            const int lo = X0 - xd, hi = X0 + iw - xd;                          // keep bytes lo <= b < hi
-            const uint32_t maskLo = lo <= 0 ? 0xFFFFFFFFu : (lo >= 4 ? 0u : 0xFFFFFFFFu << (8 * lo));
-            const uint32_t maskHi = hi >= 4 ? 0xFFFFFFFFu : (hi <= 0 ? 0u : 0xFFFFFFFFu >> (8 * (4 - hi)));
-            st[i] = sv[k] & maskLo & maskHi;
+    // phase 3: NMS inside the pixel's own cell, for the tile's own 64x32 pixels
+    const uint8_t* sb = (const uint8_t*)sc;
+    for (int q = tid; q < nq; q += 256) {
+        const int p = queue[q];
+        const int s = sb[p];
+        const int r = (p * 1821) >> 17, cidx = p - r * kFtPitch;        // p / 72 for p < 2600
+        const int lx = cidx - 4, ly = r - 1;
+        if (s == 0 || lx < 0 || lx >= kFtW || ly < 0 || ly >= kFtH) continue;
+        const int x = x0 + lx, y = y0 + ly;
+        const int gx = x - kEdge, gy = y - kEdge;                         // position inside the tested region
+        const int cj = gx / L.wCell, ci = gy / L.hCell;
+        const int rx = gx - cj * L.wCell, ry = gy - ci * L.hCell;        // position inside the cell's tested interior
+        const bool okL = rx > 0, okR = rx < L.wCell - 1, okU = ry > 0, okD = ry < L.hCell - 1;
+        const uint8_t* c = sb + p;
+        int mAll = 0;
+        if (okU) { mAll = max(mAll, (int)c[-kFtPitch]); if (okL) mAll = max(mAll, (int)c[-kFtPitch - 1]); if (okR) mAll = max(mAll, (int)c[-kFtPitch + 1]); }
+        if (okD) { mAll = max(mAll, (int)c[kFtPitch]); if (okL) mAll = max(mAll, (int)c[kFtPitch - 1]); if (okR) mAll = max(mAll, (int)c[kFtPitch + 1]); }
+        if (okL) mAll = max(mAll, (int)c[-1]);
+        if (okR) mAll = max(mAll, (int)c[1]);
+        const int fIni = (s >= iniTh && (mAll < iniTh || s > mAll)) ? 1 : 0;
+        const int fMin = (s >= minTh && (mAll < minTh || s > mAll)) ? 2 : 0;
+        if (fIni | fMin) {
+            const int cell = ci * L.nCols + cj;
+            const uint2 rec = make_uint2(((uint32_t)(fIni | fMin) << 30) | ((uint32_t)cell << 12) | ((uint32_t)ry << 6) | (uint32_t)rx,
+                                         (uint32_t)(x - kMinBorder) | ((uint32_t)(y - kMinBorder) << 12) | ((uint32_t)s << 24));
+            const int slot = atomicAdd(&on, 1);
+            if (slot < kFtW * kFtH / 4) outbuf[slot] = rec;
+            else {      // more survivors than one per 2x2 block (only possible along cell borders): append directly
+                const int g = atomicAdd(&rawCount[frame * kMaxLevels + level], 1);
+                if ((unsigned)g < L.rawCap) raw[(size_t)frame * rawPerFrame + L.rawBase + g] = rec;
+            }
+            if (fIni) cellIni[(size_t)frame * cellsPerFrame + L.cellBase + cell] = 1;
         }
     }
     __syncthreads();
-    unsigned long long mIni = 0, mMin = 0;
-    if (!skip && lane < ih) {
-        const uint8_t* row = sb + (lane + 1) * kNmsPitch + 4 + (X0 - xa);      // tested pixel ix at row[ix]
-        const uint32_t* rowd = st + (lane + 1) * (kNmsPitch / 4) + 1;
-        for (int c = 0; c < nd; ++c) {
-            if (rowd[c] == 0) continue;
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                const int ix = 4 * c + bb - (X0 - xa);
-                const int s = (rowd[c] >> (8 * bb)) & 255;
-                if (s == 0) continue;
-                const uint8_t* p = row + ix;
-                const int n0 = p[-kNmsPitch - 1], n1 = p[-kNmsPitch], n2 = p[-kNmsPitch + 1], n3 = p[-1], n4 = p[1],
-                          n5 = p[kNmsPitch - 1], n6 = p[kNmsPitch], n7 = p[kNmsPitch + 1];
-                const int mAll = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-                auto nmsAt = [&](int T) {
-                    if (s < T) return false;
-                    if (s > mAll) return true;
-                    const int t1 = T - 1;      // neighbours <= t1 are not corners at T
-                    return (n0 <= t1 || n0 < s) && (n1 <= t1 || n1 < s) && (n2 <= t1 || n2 < s) && (n3 <= t1 || n3 < s) &&
-                           (n4 <= t1 || n4 < s) && (n5 <= t1 || n5 < s) && (n6 <= t1 || n6 < s) && (n7 <= t1 || n7 < s);
-                };
-                if (nmsAt(iniTh)) mIni |= 1ull << ix;
-                if (nmsAt(minTh)) mMin |= 1ull << ix;
-            }
-        }
-    }
-    // src/Feature.cpp:875: the minTh list is used only when the iniTh list of the cell is empty
-    const bool anyIni = __ballot(mIni != 0) != 0;
-    const unsigned long long m = anyIni ? mIni : mMin;
-    const int n = __popcll(m);
-    int incl = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o); if (lane >= o) incl += tt; }
-    const int total = __shfl(incl, 63);
-    if (have && lane == 0) cellCount[(size_t)frame * cellsPerFrame + cell] = total;
-    if (n) {
-        uint32_t* out = slots + (size_t)frame * slotsPerFrame + kl.slotBase[level] + (size_t)lc * kl.slotCap[level] + (incl - n);
-        const uint8_t* row = sb + (lane + 1) * kNmsPitch + 4 + (X0 - xa);
-        unsigned long long mm = m;
-        while (mm) {
-            const int ix = __ffsll((long long)mm) - 1;
-            mm &= mm - 1;
-            // window-relative FAST coordinates (ix+3, iy+3) moved to the level's border frame (src/Feature.cpp:886-887)
-            const uint32_t x = ix + 3 + cj * wCell, y = lane + 3 + ci * hCell;
-            *out++ = x | (y << 12) | ((uint32_t)row[ix] << 24);
-        }
-    }
+    const int no = min(on, kFtW * kFtH / 4);
+    if (no == 0) return;
+    if (tid == 0) obase = atomicAdd(&rawCount[frame * kMaxLevels + level], no);
+    __syncthreads();
+    uint2* dst = raw + (size_t)frame * rawPerFrame + L.rawBase;
+    for (int i = tid; i < no; i += 256) if ((unsigned)(obase + i) < L.rawCap) dst[obase + i] = outbuf[i];
 }
 
-void launch_fast(const uint8_t* pyr, uint8_t* score, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, int cellsPerFrame,
-                 size_t slotsPerFrame, int iniTh, int minTh, uint32_t* slots, int* cellCount, int batch, hipStream_t s)
+void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, int cellsPerFrame, size_t rawPerFrame,
+                 int iniTh, int minTh, uint2* raw, int* rawCount, int* cellIni, int batch, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fast_score, dim3(tilesPerFrame, batch), dim3(256), 0, s, pyr, score, pyrFrameBytes, kl, min(iniTh, minTh));
-    hipLaunchKernelGGL(k_fast_nms, dim3((cellsPerFrame + 3) / 4, batch), dim3(256), 0, s, score, pyrFrameBytes, kl,
-                       cellsPerFrame, slotsPerFrame, iniTh, minTh, slots, cellCount);
-}
-
-// ---------------------------------------------------------------------------
-// per frame: concatenate the cells' keypoints level by level, cell-row-major, raster inside a
-// cell -- the order in which the reference appends to vToDistributeKeys (src/Feature.cpp:851-891).
-__global__ __launch_bounds__(256) void k_compact(KLevels kl, int cellsPerFrame, size_t slotsPerFrame,
-                                                 const uint32_t* __restrict__ slots, const int* __restrict__ cellCount,
-                                                 uint32_t* __restrict__ cand, int candCap, int* __restrict__ candCount)
-{
-    __shared__ int wsum[4];
-    __shared__ int carry;
-    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int* cc = cellCount + (size_t)frame * cellsPerFrame;
-    const uint32_t* sl = slots + (size_t)frame * slotsPerFrame;
-    uint32_t* out = cand + (size_t)frame * candCap;
-    int* cnt = candCount + frame * (kMaxLevels + 1);
-    int total = 0;            // running offset of this frame (uniform)
-    for (int l = 0; l < kl.nlevels; ++l) {
-        const int ncell = kl.cellBase[l + 1] - kl.cellBase[l];
-        int levelCount = 0;
-        for (int c0 = 0; c0 < ncell; c0 += 256) {
-            const int c = c0 + tid;
-            const int n = c < ncell ? cc[kl.cellBase[l] + c] : 0;
-            // block exclusive scan of n
-            int incl = n;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-            if (lane == 63) wsum[wid] = incl;
-            __syncthreads();
-            int wbase = 0, tot = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { if (i < wid) wbase += wsum[i]; tot += wsum[i]; }
-            const int off = total + levelCount + wbase + incl - n;
-            const uint32_t* src = sl + kl.slotBase[l] + (size_t)c * kl.slotCap[l];
-            for (int i = 0; i < n; ++i) if (off + i < candCap) out[off + i] = src[i];
-            levelCount += tot;
-            __syncthreads();
-        }
-        if (tid == 0) cnt[l] = levelCount;
-        total += levelCount;
-    }
-    if (tid == 0) { cnt[kMaxLevels] = total; (void)carry; }
-}
-
-void launch_compact(const KLevels& kl, int cellsPerFrame, size_t slotsPerFrame, const uint32_t* slots, const int* cellCount,
-                    uint32_t* cand, int candCap, int* candCount, int batch, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_compact, dim3(batch), dim3(256), 0, s, kl, cellsPerFrame, slotsPerFrame, slots, cellCount, cand, candCap, candCount);
+    hipLaunchKernelGGL(k_fast, dim3(tilesPerFrame, batch), dim3(256), 0, s, pyr, pyrFrameBytes, kl, cellsPerFrame, rawPerFrame,
+                       iniTh, minTh, raw, rawCount, cellIni);
 }
 
 // ---------------------------------------------------------------------------
@@ -541,16 +440,18 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     const int lane = threadIdx.x & 31;
     const int strip = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int frame = blockIdx.y;
-    const bool live = strip < kl.blurStripBase[kl.nlevels];
+    const bool live = strip < kl.lv[kl.nlevels].blurStripBase;
     int level = 0;
-    while (level + 1 < kl.nlevels && strip >= kl.blurStripBase[level + 1]) ++level;
-    const int t = live ? strip - kl.blurStripBase[level] : 0;
-    const int sy = t / kl.blurStripsX[level], sx = t - sy * kl.blurStripsX[level];
-    const int w = kl.w[level], h = kl.h[level], pitch = kl.pitch[level];
-    const int iters = live ? kl.blurIters[level] : 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; ++l) level += (l < kl.nlevels && strip >= kl.lv[l].blurStripBase) ? 1 : 0;
+    const KLevel& L = kl.lv[level];
+    const int t = live ? strip - L.blurStripBase : 0;
+    const int sy = t / L.blurStripsX, sx = t - sy * L.blurStripsX;
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const int iters = live ? L.blurIters : 0;
     const int rows = 7 * iters - 6;
-    const uint8_t* src = pyr + (size_t)frame * pyrFrameBytes + kl.offset[level];
-    uint8_t* dst = blur + (size_t)frame * pyrFrameBytes + kl.offset[level];
+    const uint8_t* src = pyr + (size_t)frame * pyrFrameBytes + L.offset;
+    uint8_t* dst = blur + (size_t)frame * pyrFrameBytes + L.offset;
     const int x = sx * 120 - 4 + 4 * lane;                 // first of this lane's 4 pixels
     const int y0 = sy * rows;
     const bool writer = lane >= 1 && lane <= 30 && x < w;
@@ -664,17 +565,28 @@ __device__ __forceinline__ void sincos_canonical(float xf, float& s, float& c)
 }
 
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                  size_t pyrFrameBytes, KLevels kl, const uint2* __restrict__ kpIn,
-                                                  const int* __restrict__ kpCount, int cap,
-                                                  ssvio_keypoint* __restrict__ kpOut, uint8_t* __restrict__ desc)
+                                                  size_t pyrFrameBytes, KLevels kl, const uint2* __restrict__ sel,
+                                                  const int* __restrict__ selCount, int selPerFrame, int cap,
+                                                  ssvio_keypoint* __restrict__ kpOut, uint8_t* __restrict__ desc, int* __restrict__ kpCount)
 {
     const int frame = blockIdx.y, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= kpCount[frame]) return;              // wave-uniform
-    const uint2 in = kpIn[(size_t)frame * cap + k];
-    const int x = in.x & 0xFFFF, y = in.x >> 16, level = in.y & 0xFF, resp = (in.y >> 8) & 0xFF;
-    const int pitch = kl.pitch[level];
-    const uint8_t* center = pyr + (size_t)frame * pyrFrameBytes + kl.offset[level] + (size_t)y * pitch + x;
+    const int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    // keypoint k of the frame in level-major order (src/Feature.cpp:537-567): locate its level list
+    const int* sc = selCount + frame * kMaxLevels;
+    int level = 0, before = 0, total = 0;
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l) {
+        const int c = l < kl.nlevels ? sc[l] : 0;
+        if (l < kl.nlevels && k >= total + c) { level = l + 1; before = total + c; }
+        total += c;
+    }
+    if (k == 0 && lane == 0) kpCount[frame] = total;
+    if (k >= total) return;                       // wave-uniform
+    const KLevel& L = kl.lv[level];
+    const uint2 in = sel[(size_t)frame * selPerFrame + L.selBase + (k - before)];
+    const int x = in.x & 0xFFFF, y = in.x >> 16, resp = (in.y >> 8) & 0xFF;
+    const int pitch = L.pitch;
+    const uint8_t* center = pyr + (size_t)frame * pyrFrameBytes + L.offset + (size_t)y * pitch + x;
     // moments: lane -> row v = lane-14 (29 rows -14..14, row 0 spans u=-15..15, others u=-d..d-1); lanes 32..63 take the
     // upper half of each row's columns to balance
     int m01 = 0, m10 = 0;
@@ -699,7 +611,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     const float ang = __fmul_rn(angle, factorPI);
     float a, b;
     sincos_canonical(ang, b, a);
-    const uint8_t* bc = blur + (size_t)frame * pyrFrameBytes + kl.offset[level] + (size_t)y * pitch + x;
+    const uint8_t* bc = blur + (size_t)frame * pyrFrameBytes + L.offset + (size_t)y * pitch + x;
     unsigned long long words[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -716,19 +628,21 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
     if (lane < 4) ((unsigned long long*)(desc + o * 32))[lane] = words[lane];
     if (lane == 0) {
         ssvio_keypoint kp;
-        const float scale = kl.scale[level];
+        const float scale = L.scale;
         kp.x = level ? __fmul_rn((float)x, scale) : (float)x;       // src/Feature.cpp:557-563
         kp.y = level ? __fmul_rn((float)y, scale) : (float)y;
-        kp.size = (float)kl.kpSize[level];
+        kp.size = (float)L.kpSize;
         kp.angle = angle; kp.response = (float)resp; kp.octave = level; kp.class_id = -1;
         kpOut[o] = kp;
     }
 }
 
 void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl,
-                     const uint2* kpIn, const int* kpCount, int cap, ssvio_keypoint* kpOut, uint8_t* desc, int batch, hipStream_t s)
+                     const uint2* sel, const int* selCount, int selPerFrame, int cap, ssvio_keypoint* kpOut, uint8_t* desc,
+                     int* kpCount, int batch, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_describe, dim3((cap + 3) / 4, batch), dim3(256), 0, s, pyr, blur, pyrFrameBytes, kl, kpIn, kpCount, cap, kpOut, desc);
+    hipLaunchKernelGGL(k_describe, dim3((cap + 3) / 4, batch), dim3(256), 0, s, pyr, blur, pyrFrameBytes, kl, sel, selCount, selPerFrame,
+                       cap, kpOut, desc, kpCount);
 }
 
 }  // namespace ssvio

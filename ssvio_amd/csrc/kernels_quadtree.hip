@@ -1,0 +1,340 @@
+// kernels_quadtree.hip -- DistributeOctTree (src/Feature.cpp:570-798, DivideNode :17-81) on the GPU:
+// one 1024-thread workgroup per (frame, pyramid level), all node state in LDS.
+//
+// The reference's linked list / per-node key vectors reduce to arrays (see geometry.cpp for the
+// same formulation on the host, which is tested against the oracle's linked-list restatement):
+//   * a node is a rectangle [x0,x1) x [y0,y1); the std::list is "reverse creation order", so list
+//     position = array index and a round rebuilds the array as [children, newest first][survivors];
+//   * keys keep their input order inside every node, so "first key with the largest response"
+//     (:783-793) = largest response, then smallest input-order key;
+//   * a round = count keys per child quadrant (LDS atomics), choose the nodes to split (all
+//     expandable nodes, or -- once size + 3*expandable > N (:707) -- the prefix of the
+//     (size desc, creation desc) order that reaches N (:716-765)), number the children by a prefix
+//     sum, relabel the keys.
+// The candidates arrive as an unordered append list (k_fast); every entry carries its position in
+// the reference's append order (cell-row-major, raster inside a cell, :851-891) as a 30-bit key, so
+// no sorting or compaction pass is needed.  The 20 -> 7 threshold fallback (:875) is resolved here:
+// an entry of a cell whose iniTh list is non-empty is used iff it passed NMS at iniTh.
+#include "common.h"
+
+namespace ssvio {
+
+constexpr int kQtThreads = 1024;
+
+struct QtShared {
+    int wsum[16];
+    int n, nE, cut, nExpand, total;
+};
+
+__device__ __forceinline__ int qt_block_scan_excl(int v, int* wsum, int& total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int base = 0; total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { if (i < wid) base += wsum[i]; total += wsum[i]; }
+    return base + incl - v;
+}
+
+// MAXA = capacity of the live node list (>= quota + 3 and >= 4 * roots); IT = nodes per thread
+template <int MAXA>
+__global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
+{
+    constexpr int IT = MAXA / kQtThreads;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // ---- LDS carve (all offsets multiples of 16)
+    unsigned long long* skeys = (unsigned long long*)smem;                 // MAXA   sort keys / final best
+    uint2* rect[2]; int* cnt[2]; int* seq[2];
+    unsigned char* p = smem + sizeof(unsigned long long) * MAXA;
+    rect[0] = (uint2*)p; p += sizeof(uint2) * MAXA; rect[1] = (uint2*)p; p += sizeof(uint2) * MAXA;
+    cnt[0] = (int*)p; p += 4 * MAXA; cnt[1] = (int*)p; p += 4 * MAXA;
+    seq[0] = (int*)p; p += 4 * MAXA; seq[1] = (int*)p; p += 4 * MAXA;
+    int* cc = (int*)p; p += 16 * MAXA;                                       // 4 child counts / child indices per node
+    int* ord = (int*)p; p += 4 * MAXA;
+    int* ord2 = (int*)p; p += 4 * MAXA;
+    int* remap = (int*)p; p += 4 * MAXA;
+    int* cpre = (int*)p; p += 4 * MAXA;
+    unsigned char* split = p; p += MAXA;
+    QtShared* sh = (QtShared*)p;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const KLevel& L = a.kl.lv[level];
+    const int N = L.quota;
+    const int H = L.h - 2 * kMinBorder;                       // maxY - minY
+    uint32_t* kval = a.kval + (size_t)frame * a.rawPerFrame + L.rawBase;
+    uint32_t* kord = a.kord + (size_t)frame * a.rawPerFrame + L.rawBase;
+    uint32_t* knode = a.knode + (size_t)frame * a.rawPerFrame + L.rawBase;
+    const uint2* raw = a.raw + (size_t)frame * a.rawPerFrame + L.rawBase;
+    const int nraw = min(a.rawCount[frame * kMaxLevels + level], (int)L.rawCap);
+    const int* cellIni = a.cellIni + (size_t)frame * a.cellsPerFrame + L.cellBase;
+    int* selCount = a.selCount + frame * kMaxLevels + level;
+    uint2* sel = a.sel + (size_t)frame * a.selPerFrame + L.selBase;
+
+    if (tid == 0) { sh->n = 0; sh->nExpand = 0; }
+    __syncthreads();
+    // ---- 0. resolve the per-cell threshold fallback, gather the used entries
+    for (int i0 = 0; i0 < nraw; i0 += kQtThreads) {
+        const int i = i0 + tid;
+        bool use = false; uint2 e = make_uint2(0, 0);
+        if (i < nraw) {
+            e = raw[i];
+            const int cell = (e.x >> 12) & 0x3FFFF, flags = e.x >> 30;
+            use = cellIni[cell] ? (flags & 1) : (flags & 2);
+        }
+        const unsigned long long m = __ballot(use);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh->n, __popcll(m));
+            base = __shfl(base, 0);
+            if (use) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1));
+                kval[pos] = e.y; kord[pos] = e.x & 0x3FFFFFFFu;
+            }
+        }
+    }
+    __syncthreads();
+    const int n = sh->n;
+    if (n == 0) { if (tid == 0) *selCount = 0; return; }
+
+    // ---- 1. roots (:574-619)
+    const int nIni = L.nIni;
+    const float hX = L.hX;
+    int cur = 0;
+    if (tid < MAXA) { cnt[0][tid] = 0; }
+    if (IT > 1) for (int j = 1; j < IT; ++j) cnt[0][tid + j * kQtThreads] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += kQtThreads) {
+        const int x = kval[k] & 0xFFF;
+        int b = (int)((float)x / hX);                            // vpInitNodes[kp.pt.x / hX], :599
+        b = min(max(b, 0), nIni - 1);
+        knode[k] = b;
+        atomicAdd(&cnt[0][b], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0;
+        for (int i = 0; i < nIni; ++i) {
+            if (cnt[0][i] > 0) {                                  // empty roots are erased (:611-614)
+                rect[0][m] = make_uint2((uint32_t)L.rootX[i] | 0u << 16, (uint32_t)L.rootX[i + 1] | (uint32_t)H << 16);
+                const int c = cnt[0][i];
+                remap[i] = m; cnt[0][m] = c; seq[0][m] = -i; ++m;
+            } else remap[i] = 0;
+        }
+        sh->total = m;
+    }
+    __syncthreads();
+    int Lsize = sh->total;
+    for (int k = tid; k < n; k += kQtThreads) knode[k] = remap[knode[k]];
+    __syncthreads();
+
+    // ---- 2. rounds
+    bool careful = false;
+    int seqCounter = 0;
+    for (int round = 0; round < 64; ++round) {
+        const int prevSize = Lsize;
+        uint2* R = rect[cur]; int* C = cnt[cur]; int* S = seq[cur];
+        uint2* R2 = rect[cur ^ 1]; int* C2 = cnt[cur ^ 1]; int* S2 = seq[cur ^ 1];
+        for (int i = tid; i < 4 * Lsize; i += kQtThreads) cc[i] = 0;
+        if (tid == 0) { sh->cut = 1 << 30; sh->nExpand = 0; }
+        __syncthreads();
+        // (b) key counts per child quadrant (DivideNode :50-69)
+        for (int k = tid; k < n; k += kQtThreads) {
+            const int pn = knode[k];
+            if (C[pn] >= 2) {
+                const uint32_t v = kval[k];
+                const int x = v & 0xFFF, y = (v >> 12) & 0xFFF;
+                const uint2 r = R[pn];
+                const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
+                const int hx = x0 + ((x1 - x0 + 1) >> 1), hy = y0 + ((y1 - y0 + 1) >> 1);   // ceil(d / 2), :21-22
+                atomicAdd(&cc[4 * pn + (x < hx ? 0 : 1) + (y < hy ? 0 : 2)], 1);
+            }
+        }
+        __syncthreads();
+        // (c) expandable nodes in list order
+        int myE[IT], myC[IT], nMine = 0;
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int i = tid * IT + j;
+            myE[j] = 0; myC[j] = 0;
+            if (i < Lsize && C[i] >= 2) {
+                myE[j] = 1;
+                myC[j] = (cc[4 * i] > 0) + (cc[4 * i + 1] > 0) + (cc[4 * i + 2] > 0) + (cc[4 * i + 3] > 0);
+                ++nMine;
+            }
+        }
+        int nE;
+        int eBase = qt_block_scan_excl(nMine, sh->wsum, nE);
+#pragma unroll
+        for (int j = 0; j < IT; ++j) if (myE[j]) ord[eBase++] = tid * IT + j;
+        __syncthreads();
+        if (nE == 0) break;                                       // nothing to divide: size stays, :703
+        int* order = ord;
+        if (careful) {
+            // largest first, ties: latest created first (= ascending sort() walked from the back, :716-717)
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const int e = tid * IT + j;
+                if (e < nE) { const int nd = ord[e]; skeys[e] = ((unsigned long long)(uint32_t)C[nd] << 32) | (uint32_t)(S[nd] + (1 << 30)); }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const int e = tid * IT + j;
+                if (e < nE) {
+                    const unsigned long long me = skeys[e];
+                    int rank = 0;
+                    for (int u = 0; u < nE; ++u) rank += skeys[u] > me ? 1 : 0;
+                    ord2[rank] = ord[e];
+                }
+            }
+            __syncthreads();
+            order = ord2;
+        }
+        // (d) which prefix of `order` is split, children numbering
+        int myD = 0, dj[IT];
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int t = tid * IT + j;
+            dj[j] = 0;
+            if (t < nE) {
+                const int nd = order[t];
+                dj[j] = (cc[4 * nd] > 0) + (cc[4 * nd + 1] > 0) + (cc[4 * nd + 2] > 0) + (cc[4 * nd + 3] > 0) - 1;
+                myD += dj[j];
+            }
+        }
+        int totD;
+        int dBase = qt_block_scan_excl(myD, sh->wsum, totD);      // exclusive sum of (children - 1)
+        {
+            int run = dBase;
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const int t = tid * IT + j;
+                if (t < nE) {
+                    cpre[t] = run + t;                            // children created before order[t]
+                    run += dj[j];
+                    if (careful && prevSize + run >= N) atomicMin(&sh->cut, t);     // :762
+                }
+            }
+        }
+        __syncthreads();
+        const int nsplit = min(sh->cut, nE - 1) + 1;
+        if (tid < MAXA) split[tid] = 0;
+        if (IT > 1) for (int j = 1; j < IT; ++j) split[tid + j * kQtThreads] = 0;
+        __syncthreads();
+        // total children = cpre[nsplit-1] + children(order[nsplit-1])
+        if (tid == 0) {
+            const int nd = order[nsplit - 1];
+            sh->total = cpre[nsplit - 1] + (cc[4 * nd] > 0) + (cc[4 * nd + 1] > 0) + (cc[4 * nd + 2] > 0) + (cc[4 * nd + 3] > 0);
+        }
+#pragma unroll
+        for (int j = 0; j < IT; ++j) { const int t = tid * IT + j; if (t < nsplit) split[order[t]] = 1; }
+        __syncthreads();
+        const int nc = sh->total;
+        // (e) survivors keep their relative order behind the new children
+        int mySurv = 0;
+#pragma unroll
+        for (int j = 0; j < IT; ++j) { const int i = tid * IT + j; if (i < Lsize && !split[i]) ++mySurv; }
+        int nsurv;
+        int sBase = qt_block_scan_excl(mySurv, sh->wsum, nsurv);
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int i = tid * IT + j;
+            if (i < Lsize && !split[i]) {
+                const int idx = nc + sBase++;
+                R2[idx] = R[i]; C2[idx] = C[i]; S2[idx] = S[i];
+                remap[i] = idx;
+            }
+        }
+        // (f) children, pushed to the front one by one (n1..n4, :655-694) => reverse creation order
+        int myExpand = 0;
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int t = tid * IT + j;
+            if (t < nsplit) {
+                const int nd = order[t];
+                const uint2 r = R[nd];
+                const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
+                const int hx = x0 + ((x1 - x0 + 1) >> 1), hy = y0 + ((y1 - y0 + 1) >> 1);
+                int m = cpre[t];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = cc[4 * nd + q];
+                    if (c > 0) {
+                        const int idx = nc - 1 - m;
+                        const int cx0 = (q & 1) ? hx : x0, cx1 = (q & 1) ? x1 : hx, cy0 = (q & 2) ? hy : y0, cy1 = (q & 2) ? y1 : hy;
+                        R2[idx] = make_uint2((uint32_t)cx0 | (uint32_t)cy0 << 16, (uint32_t)cx1 | (uint32_t)cy1 << 16);
+                        C2[idx] = c; S2[idx] = seqCounter + 1 + m;
+                        cc[4 * nd + q] = idx;                     // child index for the key relabelling
+                        if (c > 1) ++myExpand;
+                        ++m;
+                    }
+                }
+            }
+        }
+        if (myExpand) atomicAdd(&sh->nExpand, myExpand);
+        __syncthreads();
+        // (g) relabel the keys
+        for (int k = tid; k < n; k += kQtThreads) {
+            const int pn = knode[k];
+            if (split[pn]) {
+                const uint32_t v = kval[k];
+                const int x = v & 0xFFF, y = (v >> 12) & 0xFFF;
+                const uint2 r = R[pn];
+                const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
+                const int hx = x0 + ((x1 - x0 + 1) >> 1), hy = y0 + ((y1 - y0 + 1) >> 1);
+                knode[k] = cc[4 * pn + (x < hx ? 0 : 1) + (y < hy ? 0 : 2)];
+            } else knode[k] = remap[pn];
+        }
+        const int nToExpand = sh->nExpand;
+        __syncthreads();
+        cur ^= 1;
+        Lsize = nc + nsurv;
+        seqCounter += nc;
+        if (Lsize >= N || Lsize == prevSize) break;               // :703 / :769
+        if (!careful && Lsize + 3 * nToExpand > N) careful = true;   // :707
+    }
+
+    // ---- 3. best key of every node (:778-796): largest response, then first in input order
+    unsigned long long* best = skeys;
+    for (int i = tid; i < Lsize; i += kQtThreads) best[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += kQtThreads) {
+        const uint32_t v = kval[k];
+        const unsigned long long key = ((unsigned long long)(v >> 24) << 56) | ((unsigned long long)(0x3FFFFFFFu - kord[k]) << 24) | (v & 0xFFFFFFu);
+        atomicMax(&best[knode[k]], key);
+    }
+    __syncthreads();
+    for (int i = tid; i < Lsize; i += kQtThreads) {
+        const unsigned long long b = best[i];
+        const uint32_t x = ((uint32_t)b & 0xFFF) + kMinBorder, y = (((uint32_t)b >> 12) & 0xFFF) + kMinBorder;   // :905-906
+        sel[i] = make_uint2(x | (y << 16), (uint32_t)level | ((uint32_t)(b >> 56) << 8));
+    }
+    if (tid == 0) *selCount = Lsize;
+}
+
+size_t quadtree_lds_bytes(int maxa)
+{
+    return (size_t)maxa * (8 + 16 + 8 + 8 + 16 + 4 * 4 + 1) + sizeof(QtShared) + 64;
+}
+
+int launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipStream_t s)
+{
+    static bool attrSet = false;
+    if (!attrSet) {
+        (void)hipFuncSetAttribute((const void*)k_quadtree<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(1024));
+        (void)hipFuncSetAttribute((const void*)k_quadtree<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(2048));
+        attrSet = true;
+    }
+    if (maxAlive <= 1024) hipLaunchKernelGGL(k_quadtree<1024>, dim3(nlevels, batch), dim3(kQtThreads), quadtree_lds_bytes(1024), s, a);
+    else if (maxAlive <= 2048) hipLaunchKernelGGL(k_quadtree<2048>, dim3(nlevels, batch), dim3(kQtThreads), quadtree_lds_bytes(2048), s, a);
+    else return -1;
+    return 0;
+}
+
+}  // namespace ssvio
