@@ -72,6 +72,7 @@ struct KLevel {
     unsigned int rawBase, rawCap;     // this level's region of the raw candidate list of a frame (entries)
     int selBase;                      // this level's region of the selected-keypoint list of a frame
     int nIni; float hX; int rootX[5]; // quadtree roots (src/Feature.cpp:574-593)
+    int wCellMagic, hCellMagic;       // ceil(2^20 / cell size): (n * magic) >> 20 == n / cell for n < 4096
     int pad0;
 };
 struct KLevels {

@@ -246,56 +246,72 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     const int tLow = min(iniTh, minTh);
     const uint8_t* img = pyr + (size_t)frame * pyrFrameBytes + L.offset;
     const int xMaxLoad = (w + 56) & ~3;                    // last dword that is still inside the row's slack
+    // thread -> (row r0 = tid / 18, dword column c = tid % 18) once; rows r0, r0+14, r0+28 per pass (252 threads busy)
+    const int r0 = (int)(__umul24(tid, 3641u) >> 16), c0 = tid - r0 * (kFtPitch / 4);
+    const bool lane252 = tid < 252;
     {
         uint32_t ld[3];
+        const int xoff = min(x0 - 4 + 4 * c0, xMaxLoad);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int i = tid + k * 256;
-            const int r = (i * 3641) >> 16, c = i - r * (kFtPitch / 4);        // i / 18 for i < 1100
+            const int r = r0 + 14 * k;
             const int yy = min(max(y0 - 4 + r, 0), h - 1);
-            ld[k] = i < kFtRows * (kFtPitch / 4) ? *(const uint32_t*)(img + (size_t)yy * pitch + min(x0 - 4 + 4 * c, xMaxLoad)) : 0u;
+            ld[k] = (lane252 && r < kFtRows) ? *(const uint32_t*)(img + (size_t)yy * pitch + xoff) : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { const int i = tid + k * 256; if (i < kFtRows * (kFtPitch / 4)) tile[i] = ld[k]; }
+        for (int k = 0; k < 3; ++k) {
+            const int r = r0 + 14 * k;
+            if (lane252 && r < kFtRows) tile[r * (kFtPitch / 4) + c0] = ld[k];
+            if (lane252 && r < kScRows) sc[r * (kFtPitch / 4) + c0] = 0;
+        }
     }
-    for (int i = tid; i < kScRows * kFtPitch / 4; i += 256) sc[i] = 0;
     if (tid == 0) { qn = 0; on = 0; }
     __syncthreads();
     const uint8_t* tb = (const uint8_t*)tile;
     // phase 1, packed: a 9-arc always contains two ADJACENT compass pixels (ring 0,4,8,12); "some adjacent
-    // compass pair in one class" == (down|up) & (left|right) per class.  Two pixels per packed-i16 register:
-    // darker-by-more-than-T mask = (T - (v - n)) >> 15, brighter mask = (T + (v - n)) >> 15.
-    // Domain: score rows y0-1 .. y0+32, quad columns x0-4 .. x0+67 (pixels outside x0-1 .. x0+64 are dropped).
+    // compass pair in one class" == (down|up) & (left|right) per class.  Two pixels per packed-i16 register.
+    // Domain: score rows y0-1 .. y0+32 (r = 0..33), quad columns x0-4 .. x0+67 (pixels outside x0-1 .. x0+64 dropped).
     unsigned flags = 0;                                     // bit (4k+i): pixel i of this thread's quad k survives
     const short2v T2 = short2v{(short)tLow, (short)tLow};
-    constexpr int kQuads = kScRows * (kFtPitch / 4);        // 34 * 18 = 612
+    // tile (with its 1-px halo) entirely inside the tested region [19, w-20] x [19, h-20]?
+    const bool allValid = x0 - 1 >= kEdge && x0 + kFtW <= w - kEdge - 1 && y0 - 1 >= kEdge && y0 + kFtH <= h - kEdge - 1;
+    const int qc = c0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int q = tid + k * 256;
-        if (q < kQuads) {
-            const int r = (q * 3641) >> 16, qc = q - r * (kFtPitch / 4);
-            const int rowC = (r + 3) * (kFtPitch / 4);          // input row of score row r
-            const uint32_t C = tile[rowC + qc], Lf = qc > 0 ? tile[rowC + qc - 1] : 0u, Rt = qc < 17 ? tile[rowC + qc + 1] : 0u;
-            const uint32_t U = tile[rowC - 3 * (kFtPitch / 4) + qc], D = tile[rowC + 3 * (kFtPitch / 4) + qc];
-            const uint32_t lw = __builtin_amdgcn_alignbyte(C, Lf, 1);     // bytes x-3 .. x
-            const uint32_t rw = __builtin_amdgcn_alignbyte(Rt, C, 3);     // bytes x+3 .. x+6
+        const int r = min(r0 + 14 * k, kScRows - 1);
+        const bool qlive = lane252 && r0 + 14 * k < kScRows;
+        const int rowC = (r + 3) * (kFtPitch / 4);          // input row of score row r
+        const uint32_t C = tile[rowC + qc], Lf = tile[rowC + max(qc - 1, 0)], Rt = tile[rowC + min(qc + 1, 17)];
+        const uint32_t U = tile[rowC - 3 * (kFtPitch / 4) + qc], D = tile[rowC + 3 * (kFtPitch / 4) + qc];
+        const uint32_t lw = __builtin_amdgcn_alignbyte(C, Lf, 1);     // bytes x-3 .. x
+        const uint32_t rw = __builtin_amdgcn_alignbyte(Rt, C, 3);     // bytes x+3 .. x+6
+        unsigned f4 = 0;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const uint32_t sel = hlf ? 0x0c030c02u : 0x0c010c00u;      // bytes (0,1) or (2,3) -> two u16
+            auto pk = [&](uint32_t x) { return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, x, sel)); };
+            const short2v v = pk(C);
+            const short2v du = v - pk(U), dd = v - pk(D), dl = v - pk(lw), dr = v - pk(rw);
+            // some vertical AND some horizontal compass pixel darker than v-T:  min(max(du,dd), max(dl,dr)) > T
+            const short2v dark = __builtin_elementwise_min(__builtin_elementwise_max(du, dd), __builtin_elementwise_max(dl, dr));
+            // ... brighter than v+T:  max(min(du,dd), min(dl,dr)) < -T
+            const short2v brt = __builtin_elementwise_max(__builtin_elementwise_min(du, dd), __builtin_elementwise_min(dl, dr));
+            const uint32_t m = __builtin_bit_cast(uint32_t, (short2v)(((T2 - dark) | (brt + T2)) >> 15));    // sign bits
+            f4 |= ((m & 1u) | ((m >> 15) & 2u)) << (2 * hlf);
+        }
+        // keep only pixels of the score domain x0-1 .. x0+64 (quad columns 0 and 17 are partial)
+        f4 &= qc == 0 ? 8u : (qc == 17 ? 1u : 15u);
+        f4 = qlive ? f4 : 0u;
+        if (!allValid && f4) {
             const int y = y0 - 1 + r;
             const bool rowOk = y >= kEdge && y <= h - kEdge - 1;
 #pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                const uint32_t sel = hlf ? 0x0c030c02u : 0x0c010c00u;      // bytes (0,1) or (2,3) -> two u16
-                auto pk = [&](uint32_t x) { return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, x, sel)); };
-                const short2v v = pk(C);
-                const short2v du = v - pk(U), dd = v - pk(D), dl = v - pk(lw), dr = v - pk(rw);
-                const short2v darkV = ((T2 - du) >> 15) | ((T2 - dd) >> 15), darkH = ((T2 - dl) >> 15) | ((T2 - dr) >> 15);
-                const short2v brtV = ((T2 + du) >> 15) | ((T2 + dd) >> 15), brtH = ((T2 + dl) >> 15) | ((T2 + dr) >> 15);
-                const uint32_t m = __builtin_bit_cast(uint32_t, (short2v)((darkV & darkH) | (brtV & brtH)));
-                const int lx = 4 * qc + 2 * hlf - 4;             // tile-local x of the first of the two pixels
-                const int xa = x0 + lx;
-                if (rowOk && (m & 1u) && lx >= -1 && lx <= kFtW && xa >= kEdge && xa <= w - kEdge - 1) flags |= 1u << (4 * k + 2 * hlf);
-                if (rowOk && (m & 0x10000u) && lx + 1 >= -1 && lx + 1 <= kFtW && xa + 1 >= kEdge && xa + 1 <= w - kEdge - 1) flags |= 1u << (4 * k + 2 * hlf + 1);
+            for (int i = 0; i < 4; ++i) {
+                const int xa = x0 + 4 * qc + i - 4;
+                if (!(rowOk && xa >= kEdge && xa <= w - kEdge - 1)) f4 &= ~(1u << i);
             }
         }
+        flags |= f4 << (4 * k);
     }
     {   // one queue reservation per wave
         const int lane = tid & 63;
@@ -308,12 +324,11 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
             int base = 0;
             if (lane == 63) base = atomicAdd(&qn, tot);
             base = __shfl(base, 63) + incl - cnt;
+            const int e0 = r0 * kFtPitch + 4 * qc;              // byte index of this thread's first quad in the score tile
             unsigned f = flags;
             while (f) {
                 const int bit = __ffs(f) - 1; f &= f - 1;
-                const int q = tid + (bit >> 2) * 256;
-                const int r = (q * 3641) >> 16, qc = q - r * (kFtPitch / 4);
-                queue[base++] = (uint16_t)(r * kFtPitch + 4 * qc + (bit & 3));      // byte index into the score tile
+                queue[base++] = (uint16_t)(e0 + (bit >> 2) * (14 * kFtPitch) + (bit & 3));
             }
         }
     }
@@ -341,20 +356,19 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     for (int q = tid; q < nq; q += 256) {
         const int p = queue[q];
         const int s = sb[p];
-        const int r = (p * 1821) >> 17, cidx = p - r * kFtPitch;        // p / 72 for p < 2600
+        const int r = (int)(__umul24(p, 1821u) >> 17), cidx = p - r * kFtPitch;        // p / 72 for p < 2600
         const int lx = cidx - 4, ly = r - 1;
         if (s == 0 || lx < 0 || lx >= kFtW || ly < 0 || ly >= kFtH) continue;
         const int x = x0 + lx, y = y0 + ly;
         const int gx = x - kEdge, gy = y - kEdge;                         // position inside the tested region
-        const int cj = gx / L.wCell, ci = gy / L.hCell;
+        const int cj = (int)(__umul24(gx, L.wCellMagic) >> 20), ci = (int)(__umul24(gy, L.hCellMagic) >> 20);       // exact gx / wCell for gx < 4096 (host-built magic)
         const int rx = gx - cj * L.wCell, ry = gy - ci * L.hCell;        // position inside the cell's tested interior
         const bool okL = rx > 0, okR = rx < L.wCell - 1, okU = ry > 0, okD = ry < L.hCell - 1;
         const uint8_t* c = sb + p;
-        int mAll = 0;
-        if (okU) { mAll = max(mAll, (int)c[-kFtPitch]); if (okL) mAll = max(mAll, (int)c[-kFtPitch - 1]); if (okR) mAll = max(mAll, (int)c[-kFtPitch + 1]); }
-        if (okD) { mAll = max(mAll, (int)c[kFtPitch]); if (okL) mAll = max(mAll, (int)c[kFtPitch - 1]); if (okR) mAll = max(mAll, (int)c[kFtPitch + 1]); }
-        if (okL) mAll = max(mAll, (int)c[-1]);
-        if (okR) mAll = max(mAll, (int)c[1]);
+        const int nU = c[-kFtPitch], nUL = c[-kFtPitch - 1], nUR = c[-kFtPitch + 1], nD = c[kFtPitch], nDL = c[kFtPitch - 1],
+                  nDR = c[kFtPitch + 1], nL = c[-1], nR = c[1];
+        int mAll = max(max(okU ? nU : 0, okD ? nD : 0), max(okL ? nL : 0, okR ? nR : 0));
+        mAll = max(mAll, max(max((okU && okL) ? nUL : 0, (okU && okR) ? nUR : 0), max((okD && okL) ? nDL : 0, (okD && okR) ? nDR : 0)));
         const int fIni = (s >= iniTh && (mAll < iniTh || s > mAll)) ? 1 : 0;
         const int fMin = (s >= minTh && (mAll < minTh || s > mAll)) ? 2 : 0;
         if (fIni | fMin) {

@@ -146,3 +146,43 @@ def test_1080p_4000_features(mods):
     kps, desc = g.Extract(img)
     _cmp_frame(O, g, c, img, kps, desc)
     g.close()
+
+
+@pytest.mark.parametrize("kind,w,h,nf", [("noise", 640, 480, 1000), ("noise", 640, 480, 8000), ("checker", 640, 480, 2000),
+                                         ("texture", 1920, 1080, 8000), ("noise", 400, 300, 200), ("texture", 1280, 400, 1500)])
+def test_gpu_quadtree_dense_and_large_quotas(mods, kind, w, h, nf):
+    """the GPU quadtree (LDS capacities 1024 / 2048 live nodes) on very dense candidate sets, large quotas and a
+    two-root aspect ratio; every case against the oracle"""
+    S, synth, O = mods
+    if kind == "noise":
+        img = (synth.Rng(77).bytes(w * h).reshape(h, w) // 2 + synth.texture(3, h, w) // 2).astype(np.uint8)
+    elif kind == "checker":
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = ((((xx // 5) + (yy // 5)) % 2) * 140 + 40 + (synth.Rng(5).bytes(w * h).reshape(h, w) % 7)).astype(np.uint8)
+    else:
+        img = synth.texture(2024, h, w)
+    g = S.ORBextractor(nf, 1.2, 8, 20, 7); c = O.Extractor(nf, 1.2, 8, 20, 7)
+    kps, desc = g.Extract(img)
+    _cmp_frame(O, g, c, img, kps, desc)
+    for l in range(8):
+        xs, ys, rs = g.debug_candidates(l)
+        cx, cy, cr = c.level_candidates(l)
+        assert np.array_equal(xs, cx.astype(np.int32)) and np.array_equal(ys, cy.astype(np.int32)) and np.array_equal(rs, cr.astype(np.int32))
+    g.close()
+
+
+def test_host_quadtree_mode_and_oversize_quota_fallback(mods, monkeypatch):
+    """SSVIO_QUADTREE=host and quotas beyond the GPU kernel's capacity (> 2045 per level) use the host stage; same results"""
+    S, synth, O = mods
+    img = synth.texture(808, 480, 640)
+    monkeypatch.setenv("SSVIO_QUADTREE", "host")
+    g = S.ORBextractor(1000, 1.2, 8, 20, 7); c = O.Extractor(1000, 1.2, 8, 20, 7)
+    kps, desc = g.Extract(img)
+    _cmp_frame(O, g, c, img, kps, desc)
+    g.close()
+    monkeypatch.delenv("SSVIO_QUADTREE")
+    noise = (synth.Rng(9).bytes(640 * 480).reshape(480, 640) // 2 + img // 2).astype(np.uint8)
+    g = S.ORBextractor(12000, 1.2, 8, 20, 7); c = O.Extractor(12000, 1.2, 8, 20, 7)
+    kps, desc = g.Extract(noise)
+    _cmp_frame(O, g, c, noise, kps, desc)
+    g.close()
