@@ -22,10 +22,17 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
+// d += popcount(x): the accumulating form of v_bcnt_u32_b32 (one instruction per dword; left to itself the
+// compiler splits the chain into bcnt(x, 0) + v_add3_u32, 3 more instructions per descriptor pair)
+__device__ __forceinline__ void bcnt_acc(uint32_t& d, uint32_t x)
+{
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
 {
-    __shared__ uint4 tile[kTT * 2];
+    __shared__ uint4 tile[2][(kTT + 1) * 2];          // two buffers; one spare row so the row prefetch may run one past the end
     const int tid = threadIdx.x;
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int qset = a.pairs ? a.pairs[2 * pair + a.swap] : 0;
@@ -47,25 +54,38 @@ __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
         q[r][4] = hi.x; q[r][5] = hi.y; q[r][6] = hi.z; q[r][7] = hi.w;
         k1[r] = kKeyInit; k2[r] = kKeyInit;
     }
+    // train rows stream HBM/L2 -> registers -> LDS, one tile ahead of the compute
+    int buf = 0;
+    if (cBegin < cEnd) {
+        const int rows = min(kTT, cEnd - cBegin);
+        if (tid < rows * 2) tile[0][tid] = T[(size_t)cBegin * 2 + tid];
+    }
+    __syncthreads();
     for (int t0 = cBegin; t0 < cEnd; t0 += kTT) {
-        __syncthreads();
         const int rows = min(kTT, cEnd - t0);
-        if (tid < rows * 2) tile[tid] = T[(size_t)t0 * 2 + tid];
-        __syncthreads();
-#pragma unroll 2
+        const int nextRows = min(kTT, cEnd - (t0 + kTT));
+        uint4 pre = make_uint4(0, 0, 0, 0);
+        if (tid < nextRows * 2) pre = T[(size_t)(t0 + kTT) * 2 + tid];
+        const uint4* tl = tile[buf];
+        uint4 lo = tl[0], hi = tl[1];
+#pragma unroll 4
         for (int j = 0; j < rows; ++j) {
-            const uint4 lo = tile[2 * j], hi = tile[2 * j + 1];
+            const uint4 nlo = tl[2 * j + 2], nhi = tl[2 * j + 3];       // next row (the spare row after the last)
             const uint32_t idx = (uint32_t)(t0 + j);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                uint32_t d = __popc(q[r][0] ^ lo.x);
-                d += __popc(q[r][1] ^ lo.y); d += __popc(q[r][2] ^ lo.z); d += __popc(q[r][3] ^ lo.w);
-                d += __popc(q[r][4] ^ hi.x); d += __popc(q[r][5] ^ hi.y); d += __popc(q[r][6] ^ hi.z); d += __popc(q[r][7] ^ hi.w);
+                uint32_t d = 0;
+                bcnt_acc(d, q[r][0] ^ lo.x); bcnt_acc(d, q[r][1] ^ lo.y); bcnt_acc(d, q[r][2] ^ lo.z); bcnt_acc(d, q[r][3] ^ lo.w);
+                bcnt_acc(d, q[r][4] ^ hi.x); bcnt_acc(d, q[r][5] ^ hi.y); bcnt_acc(d, q[r][6] ^ hi.z); bcnt_acc(d, q[r][7] ^ hi.w);
                 const uint32_t key = (d << 23) | idx;
                 k2[r] = umed3(k1[r], k2[r], key);     // second smallest of {k1,k2,key}, k1 <= k2
                 k1[r] = min(k1[r], key);
             }
+            lo = nlo; hi = nhi;
         }
+        if (tid < nextRows * 2) tile[buf ^ 1][tid] = pre;
+        __syncthreads();
+        buf ^= 1;
     }
     uint2* out = a.partial + ((size_t)pair * a.nChunks + chunk) * a.maxRows;
 #pragma unroll

@@ -1,0 +1,28 @@
+"""GPU-box probe: matcher throughput on BASELINE configs 2/3/4 (descriptor pairs per second, VALU fraction)."""
+import sys, time, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+import ssvio_amd
+from ssvio_amd import synth, _lib as L
+PEAK = 256 * 4 * 32 * 2.4e9
+fm = ssvio_amd.FeatureMatching(None, {})
+def run(name, nsets, rows, pairs, mode, iters=20):
+    desc = np.concatenate([synth.descriptor_sets(7 + s, rows, rows)[0] for s in range(nsets)])
+    d = torch.from_numpy(desc).cuda(); cnt = torch.full((nsets,), rows, dtype=torch.int32).cuda()
+    pairs = np.asarray(pairs, np.int32)
+    for _ in range(3): fm.match_batch_dev(d, rows, rows, cnt, pairs, mode); fm.sync()
+    fm.set_profiling(True)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(iters): fm.match_batch_dev(d, rows, rows, cnt, pairs, mode)
+    fm.sync(); dt = (time.perf_counter() - t) / iters
+    kt = fm.kernel_times(); fm.set_profiling(False)
+    npairs = len(pairs) * rows * rows * (2 if mode == 2 else 1)
+    ms, n = kt["k_hamming_knn2"]
+    print("%-34s wall %8.1f us  knn2 %8.1f us/launch  %.3e desc-pairs/s (kernel)  valu frac %.3f  finalize %.1f us" % (
+        name, dt * 1e6, ms * 1e3 / n, rows * rows * len(pairs) / (ms * 1e-3 / n), 19 * rows * rows * len(pairs) / (ms * 1e-3 / n) / PEAK,
+        kt["k_match_finalize"][0] * 1e3 / kt["k_match_finalize"][1]))
+run("cfg2 64 pairs 1000x1000 bf", 64, 1000, [[f, (f - 1) % 64] for f in range(64)], 0)
+run("cfg3 1 pair 4000x4000 knn2", 2, 4000, [[0, 1]], 1)
+run("cfg4 64 pairs 4000x4000 crosscheck", 65, 4000, [[0, k + 1] for k in range(64)], 2)
+run("cfg5-like 256 pairs 8000x8000 bf", 24, 8000, [[i, j] for i in range(24) for j in range(i)][:256], 0, iters=5)
+fm.close()
