@@ -767,7 +767,7 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
     }
     {
         ProfScope p(m->prof, "k_match_finalize", s);
-        launch_finalize(f, npairs, s);
+        launch_finalize(f, npairs, maxQ, maxT, s);
     }
     m->lastPairs = npairs; m->lastMaxRows = maxRows;
     return SSVIO_OK;

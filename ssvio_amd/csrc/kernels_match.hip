@@ -29,10 +29,45 @@ __device__ __forceinline__ void bcnt_acc(uint32_t& d, uint32_t x)
     asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d) : "v"(x));
 }
 
+// d = popcount(x)
+__device__ __forceinline__ uint32_t bcnt0(uint32_t x)
+{
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(x));
+    return d;
+}
+
+// one train row against the lane's R queries: ComputeMatchingScore + the best/second-best update
+template <int R>
+__device__ __forceinline__ void row_update(const uint32_t (&q)[R][8], uint32_t (&k1)[R], uint32_t (&k2)[R],
+                                           const uint4 lo, const uint4 hi, const uint32_t idx)
+{
+    // the R chains are interleaved dword by dword (volatile asm keeps the order): a v_bcnt that directly follows
+    // the v_xor it depends on costs ~0.5 cycle more than one issued a few instructions later
+    const uint32_t t[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t d[R], x[R];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x[r]) : "v"(q[r][i]), "v"(t[i]));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (i == 0) asm volatile("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d[r]) : "v"(x[r]));
+            else asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(d[r]) : "v"(x[r]));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t key = (d[r] << 23) | idx;
+        k2[r] = umed3(k1[r], k2[r], key);     // second smallest of {k1,k2,key}, k1 <= k2
+        k1[r] = min(k1[r], key);
+    }
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
 {
-    __shared__ uint4 tile[2][(kTT + 1) * 2];          // two buffers; one spare row so the row prefetch may run one past the end
+    __shared__ uint4 tile[2][kTT * 2];                // two buffers: the next tile lands while this one is consumed
     const int tid = threadIdx.x;
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int qset = a.pairs ? a.pairs[2 * pair + a.swap] : 0;
@@ -67,21 +102,11 @@ __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
         uint4 pre = make_uint4(0, 0, 0, 0);
         if (tid < nextRows * 2) pre = T[(size_t)(t0 + kTT) * 2 + tid];
         const uint4* tl = tile[buf];
-        uint4 lo = tl[0], hi = tl[1];
+        if (rows == kTT) {
 #pragma unroll 4
-        for (int j = 0; j < rows; ++j) {
-            const uint4 nlo = tl[2 * j + 2], nhi = tl[2 * j + 3];       // next row (the spare row after the last)
-            const uint32_t idx = (uint32_t)(t0 + j);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                uint32_t d = 0;
-                bcnt_acc(d, q[r][0] ^ lo.x); bcnt_acc(d, q[r][1] ^ lo.y); bcnt_acc(d, q[r][2] ^ lo.z); bcnt_acc(d, q[r][3] ^ lo.w);
-                bcnt_acc(d, q[r][4] ^ hi.x); bcnt_acc(d, q[r][5] ^ hi.y); bcnt_acc(d, q[r][6] ^ hi.z); bcnt_acc(d, q[r][7] ^ hi.w);
-                const uint32_t key = (d << 23) | idx;
-                k2[r] = umed3(k1[r], k2[r], key);     // second smallest of {k1,k2,key}, k1 <= k2
-                k1[r] = min(k1[r], key);
-            }
-            lo = nlo; hi = nhi;
+            for (int j = 0; j < kTT; ++j) row_update<R>(q, k1, k2, tl[2 * j], tl[2 * j + 1], (uint32_t)(t0 + j));
+        } else {
+            for (int j = 0; j < rows; ++j) row_update<R>(q, k1, k2, tl[2 * j], tl[2 * j + 1], (uint32_t)(t0 + j));
         }
         if (tid < nextRows * 2) tile[buf ^ 1][tid] = pre;
         __syncthreads();
@@ -124,6 +149,21 @@ __device__ __forceinline__ void merge_chunks(const uint2* __restrict__ partial, 
     }
 }
 
+// fold the nChunks partial lists of every pair into chunk 0 (each thread owns one query row, so in place is safe);
+// k_match_finalize then reads one uint2 per row instead of walking the chunks in a single workgroup
+__global__ __launch_bounds__(256) void k_match_merge(uint2* partial, int nChunks, int maxRows, const int* counts,
+                                                     const int* pairs, int side)
+{
+    const int pair = blockIdx.y;
+    const int set = pairs ? pairs[2 * pair + side] : 0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= counts[set]) return;
+    uint2* P = partial + (size_t)pair * nChunks * maxRows;
+    uint32_t k1, k2;
+    merge_chunks(P, nChunks, maxRows, i, k1, k2);
+    P[i] = make_uint2(k1, k2);
+}
+
 __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -152,8 +192,8 @@ __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
     const int qset = a.pairs ? a.pairs[2 * pair] : 0;
     const int tset = a.pairs ? a.pairs[2 * pair + 1] : 0;
     const int nq = a.qcounts[qset], nt = a.tcounts[tset];
-    const uint2* P = a.partial + (size_t)pair * a.nChunks * a.maxRows;
-    const uint2* PR = a.partialRev ? a.partialRev + (size_t)pair * a.nChunksRev * a.maxRows : nullptr;
+    const uint2* P = a.partial + (size_t)pair * a.pairStride;
+    const uint2* PR = a.partialRev ? a.partialRev + (size_t)pair * a.pairStrideRev : nullptr;
     ssvio_dmatch* out = a.out ? a.out + (size_t)pair * a.maxRows : nullptr;
     if (nq <= 0 || nt <= 0) { if (tid == 0 && a.nout) a.nout[pair] = 0; return; }   // src/FeatureMatching.cpp:25-27
 
@@ -209,8 +249,20 @@ __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
     if (tid == 0) a.nout[pair] = written;
 }
 
-void launch_finalize(const FinalizeArgs& a, int npairs, hipStream_t s)
+void launch_finalize(const FinalizeArgs& a0, int npairs, int maxQ, int maxT, hipStream_t s)
 {
+    FinalizeArgs a = a0;
+    a.pairStride = (size_t)a.nChunks * a.maxRows; a.pairStrideRev = (size_t)a.nChunksRev * a.maxRows;
+    if (a.nChunks > 1) {
+        hipLaunchKernelGGL(k_match_merge, dim3((maxQ + 255) / 256, npairs), dim3(256), 0, s,
+                           const_cast<uint2*>(a.partial), a.nChunks, a.maxRows, a.qcounts, a.pairs, 0);
+        a.nChunks = 1;
+    }
+    if (a.partialRev && a.nChunksRev > 1) {
+        hipLaunchKernelGGL(k_match_merge, dim3((maxT + 255) / 256, npairs), dim3(256), 0, s,
+                           const_cast<uint2*>(a.partialRev), a.nChunksRev, a.maxRows, a.tcounts, a.pairs, 1);
+        a.nChunksRev = 1;
+    }
     hipLaunchKernelGGL(k_match_finalize, dim3(npairs), dim3(256), 0, s, a);
 }
 

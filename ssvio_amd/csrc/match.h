@@ -19,6 +19,7 @@ struct FinalizeArgs {
     const uint2* partial; int nChunks;
     const uint2* partialRev; int nChunksRev;
     int maxRows;
+    size_t pairStride, pairStrideRev;           // entries between consecutive pairs (filled by launch_finalize)
     const int* qcounts; const int* tcounts; const int* pairs;
     int mode; int threshold; float nnRatio;
     ssvio_dmatch* out; int* nout;               // [pair][maxRows], [pair]
@@ -26,6 +27,6 @@ struct FinalizeArgs {
 };
 
 void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);
-void launch_finalize(const FinalizeArgs& a, int npairs, hipStream_t s);
+void launch_finalize(const FinalizeArgs& a, int npairs, int maxQ, int maxT, hipStream_t s);
 
 }  // namespace ssvio
