@@ -97,10 +97,19 @@ int  ssvio_orb_extract_batch(ssvio_orb* h, const uint8_t* imgs, int batch, int c
                              ssvio_keypoint* kps, uint8_t* desc, int cap, int* n);
 /* Same with device-resident frames; results stay in HBM inside the handle:
  * d_kps[batch][cap'], d_desc[batch][cap'][32], d_n[batch] with cap' = ssvio_orb_max_keypoints().
- * The call returns after the work is complete (the quadtree stage needs the host in
- * this version), results valid until the next call on the handle. */
+ * The call returns after the work is complete; results valid until the next call on the handle. */
 int  ssvio_orb_extract_batch_dev(ssvio_orb* h, const void* d_imgs, int batch, int channels,
                                  int width, int height, int stride, size_t frame_stride);
+/* Pipelined form ("sustained fps (pipelined)"): only enqueues the work on the
+ * handle's stream and returns.  The device results may be consumed by later work on the same stream
+ * (bind the matcher to it: ssvio_orb_get_stream -> ssvio_matcher_set_stream); the host-visible counts
+ * (ssvio_orb_last_counts / ssvio_orb_fetch_results) wait for completion themselves, ssvio_orb_sync
+ * does so explicitly.  Not available with the host quadtree (SSVIO_QUADTREE=host), which waits anyway. */
+int  ssvio_orb_extract_batch_dev_async(ssvio_orb* h, const void* d_imgs, int batch, int channels,
+                                       int width, int height, int stride, size_t frame_stride);
+int  ssvio_orb_sync(ssvio_orb* h);
+/* the hipStream_t the handle enqueues on (its own unless ssvio_orb_set_stream changed it) */
+int  ssvio_orb_get_stream(ssvio_orb* h, void** hip_stream);
 int  ssvio_orb_device_results(ssvio_orb* h, const void** d_kps, const void** d_desc, const int32_t** d_n,
                               int* cap_per_frame);
 /* copy the device-resident results of the last *_dev call to the host */
@@ -128,6 +137,9 @@ int  ssvio_distribute_octtree(const float* xs, const float* ys, const float* res
  * ssvio_orb_kernel_times: fills up to cap entries; names are static strings. */
 int  ssvio_orb_set_profiling(ssvio_orb* h, int enable);
 int  ssvio_orb_kernel_times(ssvio_orb* h, const char** names, double* total_ms, int32_t* launches, int cap, int* count);
+/* bracket only the kernel of this name (NULL or "" = every kernel): two events per call instead of two per
+ * kernel, for timing one kernel inside a throughput run without slowing the stream down */
+int  ssvio_orb_profile_only(ssvio_orb* h, const char* kernel);
 /* bind the handle to a caller-owned hipStream_t (NULL restores the handle's own stream) */
 int  ssvio_orb_set_stream(ssvio_orb* h, void* hip_stream);
 
@@ -139,6 +151,7 @@ void ssvio_matcher_destroy(ssvio_matcher* m);
 int  ssvio_matcher_set_stream(ssvio_matcher* m, void* hip_stream);
 int  ssvio_matcher_set_profiling(ssvio_matcher* m, int enable);
 int  ssvio_matcher_kernel_times(ssvio_matcher* m, const char** names, double* total_ms, int32_t* launches, int cap, int* count);
+int  ssvio_matcher_profile_only(ssvio_matcher* m, const char* kernel);
 
 /* FeatureMatching::MatchByBruteForce(desp1, desp2, matches), src/FeatureMatching.cpp:20-55:
  * BFMatcher(NORM_HAMMING).match + keep dist < max(2*min_dist, 30).  Rows are 32 bytes, `stride`

@@ -45,6 +45,9 @@ SYMBOLS = {
     "ssvio_orb_extract_rgb": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "ssvio_orb_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _sz, _vp, _vp, _i, _vp]),
     "ssvio_orb_extract_batch_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _sz]),
+    "ssvio_orb_extract_batch_dev_async": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _sz]),
+    "ssvio_orb_sync": (_i, [_vp]),
+    "ssvio_orb_get_stream": (_i, [_vp, _vp]),
     "ssvio_orb_device_results": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "ssvio_orb_fetch_results": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
     "ssvio_orb_last_counts": (_i, [_vp, _i, _vp]),
@@ -54,6 +57,8 @@ SYMBOLS = {
     "ssvio_distribute_octtree": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "ssvio_orb_set_profiling": (_i, [_vp, _i]),
     "ssvio_orb_kernel_times": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "ssvio_orb_profile_only": (_i, [_vp, C.c_char_p]),
+    "ssvio_matcher_profile_only": (_i, [_vp, C.c_char_p]),
     "ssvio_orb_set_stream": (_i, [_vp, _vp]),
     "ssvio_matcher_create": (_i, [_i, _f, _i, _vp]),
     "ssvio_matcher_destroy": (None, [_vp]),

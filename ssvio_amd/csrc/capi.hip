@@ -142,7 +142,9 @@ struct ssvio_orb {
     PyramidGeom geom{};
     KLevels kl{};
     hipStream_t own = nullptr, stream = nullptr;
-    hipEvent_t evCand = nullptr;
+    hipStream_t side = nullptr;                       // k_blur runs here, beside k_fast / k_quadtree
+    hipEvent_t evCand = nullptr, evFork = nullptr, evJoin = nullptr;
+    bool pending = false;                             // an _async call has not been waited for yet
     int batchCap = 0;
     int kpCap = 0;                 // keypoints per frame
     int candCap = 0;               // candidates per frame (all levels)
@@ -154,13 +156,13 @@ struct ssvio_orb {
     uint2* d_sel = nullptr; int* d_selCount = nullptr;                                  // selected keypoints per level
     int* d_kpCount = nullptr;
     ssvio_keypoint* d_kpOut = nullptr; uint8_t* d_desc = nullptr;
-    int* h_kpCount = nullptr;
+    int* h_kpCount = nullptr; int* d_kpCountHost = nullptr;   // pinned host array and its device address
     bool hostQuadtree = false;     // SSVIO_QUADTREE=host, or a level quota beyond the GPU kernel's LDS capacity
     int maxAlive = 0;
     // host copies for the host quadtree mode and the debug taps (lazily sized)
     std::vector<uint2> h_raw; std::vector<int> h_rawCount, h_cellIni; std::vector<uint2> h_sel; std::vector<int> h_selCount;
     bool hostRawValid = false;
-    KernelProfiler prof;
+    KernelProfiler prof; std::string profOnly;
     std::unique_ptr<WorkerPool> pool;
     int lastBatch = 0;
     bool haveResults = false;
@@ -251,7 +253,8 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
         SSVIO_HIP(hipMalloc(&h->d_kpCount, B * sizeof(int)));
         SSVIO_HIP(hipMalloc(&h->d_kpOut, B * h->kpCap * sizeof(ssvio_keypoint)));
         SSVIO_HIP(hipMalloc(&h->d_desc, B * h->kpCap * 32));
-        SSVIO_HIP(hipHostMalloc(&h->h_kpCount, B * sizeof(int), hipHostMallocDefault));
+        SSVIO_HIP(hipHostMalloc(&h->h_kpCount, B * sizeof(int), hipHostMallocMapped));
+        SSVIO_HIP(hipHostGetDevicePointer((void**)&h->d_kpCountHost, h->h_kpCount, 0));
         h->batchCap = batch;
     }
     if (inBytes > h->inBytes) {
@@ -341,13 +344,12 @@ static int orb_host_quadtree(ssvio_orb* h, int batch)
 
 // the whole pipeline for `batch` frames whose level-0 images are already in d_pyr; everything is
 // enqueued on the stream, the host only waits for the per-frame keypoint counts at the end
-static int orb_run(ssvio_orb* h, int batch)
+static int orb_run(ssvio_orb* h, int batch, bool wait = true)
 {
     const PyramidGeom& g = h->geom;
     hipStream_t s = h->stream;
     h->hostRawValid = false;
-    SSVIO_HIP(hipMemsetAsync(h->d_rawCount, 0, (size_t)batch * kMaxLevels * sizeof(int), s));
-    SSVIO_HIP(hipMemsetAsync(h->d_cellIni, 0, (size_t)batch * g.cellsPerFrame * sizeof(int), s));
+    // d_rawCount / d_cellIni were cleared by k_level0
     for (int l = 1; l < g.nlevels; ++l) {
         ProfScope p(h->prof, "k_resize", s);
         launch_resize(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], h->qTabOff[l], (int)h->quadOk[l], h->resizeRows[l], batch, s);
@@ -357,6 +359,15 @@ static int orb_run(ssvio_orb* h, int batch)
         launch_fast(h->d_pyr, g.frameBytes, h->kl, g.fastTilesPerFrame, g.cellsPerFrame, g.slotsPerFrame, h->tab.iniTh, h->tab.minTh,
                     h->d_raw, h->d_rawCount, h->d_cellIni, batch, s);
     }
+    // the blur depends on the pyramid only: it runs on the side stream beside k_quadtree (one workgroup per frame-level,
+    // which leaves most of the chip idle), and k_describe waits for both
+    SSVIO_HIP(hipEventRecord(h->evFork, s));
+    SSVIO_HIP(hipStreamWaitEvent(h->side, h->evFork, 0));
+    {
+        ProfScope p(h->prof, "k_blur", h->side);
+        launch_blur(h->d_pyr, h->d_blur, g.frameBytes, h->kl, g.blurStripsPerFrame, batch, h->side);
+    }
+    SSVIO_HIP(hipEventRecord(h->evJoin, h->side));
     if (!h->hostQuadtree) {
         QtArgs a{};
         a.kl = h->kl; a.raw = h->d_raw; a.rawCount = h->d_rawCount; a.cellIni = h->d_cellIni;
@@ -366,20 +377,27 @@ static int orb_run(ssvio_orb* h, int batch)
         ProfScope p(h->prof, "k_quadtree", s);
         if (launch_quadtree(a, h->maxAlive, g.nlevels, batch, s)) { set_error("internal: quadtree capacity"); return SSVIO_ERR_INVALID; }
     }
-    {
-        // the blur does not depend on the keypoints
-        ProfScope p(h->prof, "k_blur", s);
-        launch_blur(h->d_pyr, h->d_blur, g.frameBytes, h->kl, g.blurStripsPerFrame, batch, s);
-    }
     if (h->hostQuadtree) { const int rc = orb_host_quadtree(h, batch); if (rc) return rc; }
+    SSVIO_HIP(hipStreamWaitEvent(s, h->evJoin, 0));
     {
         ProfScope p(h->prof, "k_describe", s);
         launch_describe(h->d_pyr, h->d_blur, g.frameBytes, h->kl, h->d_sel, h->d_selCount, h->kpCap, h->kpCap, h->d_kpOut, h->d_desc,
-                        h->d_kpCount, batch, s);
+                        h->d_kpCount, h->d_kpCountHost, batch, s);
     }
-    SSVIO_HIP(hipMemcpyAsync(h->h_kpCount, h->d_kpCount, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    h->lastBatch = batch; h->haveResults = true;
+    // the counts reach the host through k_describe's stores into the pinned, device-mapped h_kpCount
+    h->lastBatch = batch; h->haveResults = true; h->pending = true;
+    if (wait) { SSVIO_HIP(hipStreamSynchronize(s)); h->pending = false; }
+    return SSVIO_OK;
+}
+
+// host-visible results (h_kpCount, profiler records) are complete after this
+static int orb_wait(ssvio_orb* h)
+{
+    if (!h->pending) return SSVIO_OK;
+    SSVIO_HIP(hipSetDevice(h->device));
+    SSVIO_HIP(hipStreamSynchronize(h->stream));
+    h->pending = false;
+    h->prof.resolve();
     return SSVIO_OK;
 }
 
@@ -410,7 +428,9 @@ int ssvio_orb_create(const ssvio_orb_params* params, int device, ssvio_orb** out
     SSVIO_HIP(hipSetDevice(device));
     ssvio_orb* h = new ssvio_orb();
     h->device = device; h->tab = t;
-    if (hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->evCand, hipEventDisableTiming) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evCand, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess) {
         set_error("cannot create HIP stream/event"); delete h; return SSVIO_ERR_HIP;
     }
     h->stream = h->own;
@@ -429,6 +449,9 @@ void ssvio_orb_destroy(ssvio_orb* h)
     orb_free_buffers(h);
     dfree(h->d_tabs);
     if (h->evCand) (void)hipEventDestroy(h->evCand);
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
+    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->own) (void)hipStreamDestroy(h->own);
     delete h;
 }
@@ -468,8 +491,8 @@ int ssvio_orb_level_geometry(ssvio_orb* h, int width, int height, int level, int
     return SSVIO_OK;
 }
 
-int ssvio_orb_extract_batch_dev(ssvio_orb* h, const void* d_imgs, int batch, int channels,
-                                int width, int height, int stride, size_t frame_stride)
+static int orb_extract_dev(ssvio_orb* h, const void* d_imgs, int batch, int channels,
+                           int width, int height, int stride, size_t frame_stride, bool wait)
 {
     if (orb_check(h)) return SSVIO_ERR_INVALID;
     if (channels != 1 && channels != 3) { set_error("channels must be 1 or 3"); return SSVIO_ERR_INVALID; }
@@ -481,13 +504,35 @@ int ssvio_orb_extract_batch_dev(ssvio_orb* h, const void* d_imgs, int batch, int
     const PyramidGeom& g = h->geom;
     {
         ProfScope p(h->prof, channels == 3 ? "k_rgb2gray" : "k_copy_gray", h->stream);
-        if (channels == 3) launch_rgb2gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch, h->stream);
-        else launch_copy_gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch, h->stream);
+        if (channels == 3) launch_rgb2gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
+                                  h->d_rawCount, batch * kMaxLevels, h->d_cellIni, batch * g.cellsPerFrame, h->stream);
+        else launch_copy_gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
+                                  h->d_rawCount, batch * kMaxLevels, h->d_cellIni, batch * g.cellsPerFrame, h->stream);
     }
-    rc = orb_run(h, batch);
+    rc = orb_run(h, batch, wait);
     if (rc) return rc;
-    SSVIO_HIP(hipStreamSynchronize(h->stream));
-    h->prof.resolve();
+    if (wait) h->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_orb_extract_batch_dev(ssvio_orb* h, const void* d_imgs, int batch, int channels,
+                                int width, int height, int stride, size_t frame_stride)
+{ return orb_extract_dev(h, d_imgs, batch, channels, width, height, stride, frame_stride, true); }
+
+int ssvio_orb_extract_batch_dev_async(ssvio_orb* h, const void* d_imgs, int batch, int channels,
+                                      int width, int height, int stride, size_t frame_stride)
+{ return orb_extract_dev(h, d_imgs, batch, channels, width, height, stride, frame_stride, false); }
+
+int ssvio_orb_sync(ssvio_orb* h)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    return orb_wait(h);
+}
+
+int ssvio_orb_get_stream(ssvio_orb* h, void** hip_stream)
+{
+    if (orb_check(h) || !hip_stream) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    *hip_stream = (void*)h->stream;
     return SSVIO_OK;
 }
 
@@ -495,6 +540,7 @@ int ssvio_orb_fetch_results(ssvio_orb* h, int batch, ssvio_keypoint* kps, uint8_
 {
     if (orb_check(h)) return SSVIO_ERR_INVALID;
     if (!n) { set_error("null count array"); return SSVIO_ERR_INVALID; }
+    { const int rc = orb_wait(h); if (rc) return rc; }
     if (batch > h->lastBatch || !h->haveResults) {
         if (h->lastBatch == 0) { for (int f = 0; f < batch; ++f) n[f] = 0; return SSVIO_OK; }
         set_error("no results for %d frames (last call had %d)", batch, h->lastBatch); return SSVIO_ERR_INVALID;
@@ -518,6 +564,7 @@ int ssvio_orb_fetch_results(ssvio_orb* h, int batch, ssvio_keypoint* kps, uint8_
 int ssvio_orb_last_counts(ssvio_orb* h, int batch, int* n)
 {
     if (orb_check(h) || !n) return SSVIO_ERR_INVALID;
+    { const int rc = orb_wait(h); if (rc) return rc; }
     for (int f = 0; f < batch; ++f) n[f] = (h->haveResults && f < h->lastBatch) ? h->h_kpCount[f] : 0;
     return SSVIO_OK;
 }
@@ -548,8 +595,10 @@ int ssvio_orb_extract_batch(ssvio_orb* h, const uint8_t* imgs, int batch, int ch
                                    rowBytes, height, hipMemcpyHostToDevice, h->stream));
     {
         ProfScope p(h->prof, channels == 3 ? "k_rgb2gray" : "k_copy_gray", h->stream);
-        if (channels == 3) launch_rgb2gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch, h->stream);
-        else launch_copy_gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch, h->stream);
+        if (channels == 3) launch_rgb2gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
+                                  h->d_rawCount, batch * kMaxLevels, h->d_cellIni, batch * g.cellsPerFrame, h->stream);
+        else launch_copy_gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
+                                  h->d_rawCount, batch * kMaxLevels, h->d_cellIni, batch * g.cellsPerFrame, h->stream);
     }
     rc = orb_run(h, batch);
     if (rc) return rc;
@@ -668,6 +717,14 @@ int ssvio_orb_kernel_times(ssvio_orb* h, const char** names, double* total_ms, i
     return prof_out(h->prof, names, total_ms, launches, cap, count);
 }
 
+int ssvio_orb_profile_only(ssvio_orb* h, const char* kernel)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    h->profOnly = kernel ? kernel : "";
+    h->prof.only = h->profOnly.empty() ? nullptr : h->profOnly.c_str();
+    return SSVIO_OK;
+}
+
 int ssvio_orb_set_stream(ssvio_orb* h, void* hip_stream)
 {
     if (orb_check(h)) return SSVIO_ERR_INVALID;
@@ -693,7 +750,8 @@ struct ssvio_matcher {
     int32_t* d_raw = nullptr; size_t rawCap = 0;
     int* d_nout = nullptr; size_t noutCap = 0;
     int* d_pairs = nullptr; size_t pairsCap = 0;
-    KernelProfiler prof;
+    std::vector<int32_t> h_pairs;                     // what d_pairs holds (an unchanged pair list is not uploaded again)
+    KernelProfiler prof; std::string profOnly;
     int lastPairs = 0, lastMaxRows = 0;
 };
 
@@ -710,12 +768,12 @@ template <typename T> static int grow(T*& p, size_t& cap, size_t need, hipStream
 
 static int mt_check(ssvio_matcher* m) { if (!m) { set_error("null matcher handle"); return SSVIO_ERR_INVALID; } return SSVIO_OK; }
 
-// choose how many pieces the train set is cut into so that the launch has >= ~1024 workgroups
+// choose how many pieces the train set is cut into so that the launch has >= ~2048 workgroups (two per SIMD)
 static void pick_chunks(int maxQ, int maxT, int npairs, int& nChunks, int& chunkRows)
 {
     const int R = maxQ > 2048 ? 4 : maxQ > 512 ? 2 : 1;
     const long qBlocks = (long)((maxQ + 256 * R - 1) / (256 * R)) * npairs;
-    long want = (1024 + qBlocks - 1) / qBlocks;
+    long want = (2048 + qBlocks - 1) / qBlocks;
     const long maxChunks = std::max(1, (maxT + 127) / 128);
     want = std::min<long>(std::min<long>(want, maxChunks), 64);
     nChunks = (int)std::max<long>(want, 1);
@@ -854,6 +912,14 @@ int ssvio_matcher_set_stream(ssvio_matcher* m, void* hip_stream)
     return SSVIO_OK;
 }
 
+int ssvio_matcher_profile_only(ssvio_matcher* m, const char* kernel)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    m->profOnly = kernel ? kernel : "";
+    m->prof.only = m->profOnly.empty() ? nullptr : m->profOnly.c_str();
+    return SSVIO_OK;
+}
+
 int ssvio_matcher_set_profiling(ssvio_matcher* m, int enable)
 {
     if (mt_check(m)) return SSVIO_ERR_INVALID;
@@ -896,9 +962,16 @@ int ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_r
     if (mode < 0 || mode > 2) { set_error("mode must be 0..2"); return SSVIO_ERR_INVALID; }
     if (max_rows > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
     SSVIO_HIP(hipSetDevice(m->device));
-    int rc = grow(m->d_pairs, m->pairsCap, (size_t)npairs * 2, m->stream); if (rc) return rc;
-    SSVIO_HIP(hipMemcpyAsync(m->d_pairs, pairs, (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    SSVIO_HIP(hipStreamSynchronize(m->stream));        // pairs may be pageable caller memory
+    int rc = SSVIO_OK;
+    if (m->h_pairs.size() != (size_t)npairs * 2 || memcmp(m->h_pairs.data(), pairs, (size_t)npairs * 2 * sizeof(int32_t)) != 0) {
+        const size_t capBefore = m->pairsCap;
+        rc = grow(m->d_pairs, m->pairsCap, (size_t)npairs * 2, m->stream); if (rc) return rc;
+        (void)capBefore;
+        SSVIO_HIP(hipStreamSynchronize(m->stream));    // earlier launches may still read the old list
+        m->h_pairs.assign(pairs, pairs + (size_t)npairs * 2);
+        SSVIO_HIP(hipMemcpyAsync(m->d_pairs, m->h_pairs.data(), (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        SSVIO_HIP(hipStreamSynchronize(m->stream));
+    }
     rc = match_run(m, (const uint8_t*)d_desc, set_stride_rows, d_counts, (const uint8_t*)d_desc, set_stride_rows, d_counts,
                    m->d_pairs, npairs, max_rows, max_rows, mode);
     if (rc) return rc;

@@ -115,6 +115,7 @@ struct KernelProfiler {
     struct Rec { const char* name; hipEvent_t a, b; };
     struct Stat { const char* name; double ms; int launches; };
     bool enabled = false;
+    const char* only = nullptr;   // when set, only the kernel of this name is bracketed
     std::vector<Rec> pending;
     std::vector<hipEvent_t> pool;
     std::vector<Stat> stats;
@@ -128,16 +129,17 @@ struct KernelProfiler {
 
 struct ProfScope {
     KernelProfiler& p; hipStream_t s;
-    ProfScope(KernelProfiler& p_, const char* name, hipStream_t s_) : p(p_), s(s_) { if (p.enabled) p.begin(name, s); }
-    ~ProfScope() { if (p.enabled) p.end(s); }
+    bool on;
+    ProfScope(KernelProfiler& p_, const char* name, hipStream_t s_) : p(p_), s(s_), on(p_.enabled && (!p_.only || strcmp(p_.only, name) == 0)) { if (on) p.begin(name, s); }
+    ~ProfScope() { if (on) p.end(s); }
 };
 
 // ---------------------------------------------------------------- kernel launchers (defined in *.hip)
 // candidates are packed as x | y<<12 | score<<24 (x,y relative to minBorder)
 void launch_rgb2gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
-                     uint8_t* pyr, size_t pyrFrameBytes, int pitch0, hipStream_t s);
+                     uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s);
 void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
-                      uint8_t* pyr, size_t pyrFrameBytes, int pitch0, hipStream_t s);
+                      uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s);
 void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int level, const int16_t* tabs,
                    size_t xTabOff, size_t yTabOff, size_t quadTabOff, int mode /*0 generic, 1 quad, 2 area 2x2*/, int rows, int batch, hipStream_t s);
 // FAST: appends {key, val} per NMS survivor to the level's raw list; key = flags<<30 | cell<<12 | iy<<6 | ix
@@ -149,6 +151,6 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const 
 // sel: per level lists {x | y<<16, level | resp<<8} at f*selPerFrame + selBase[l]; selCount[f][kMaxLevels]
 void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl,
                      const uint2* sel, const int* selCount, int selPerFrame, int cap, ssvio_keypoint* kpOut, uint8_t* desc,
-                     int* kpCount, int batch, hipStream_t s);
+                     int* kpCount, int* kpCountHost /* device view of pinned host memory */, int batch, hipStream_t s);
 
 }  // namespace ssvio

@@ -28,8 +28,16 @@ __device__ __forceinline__ int refl_clamp(int p, int n) { return min(max(refl101
 // x0 = 4*qi - 4 .. x0+3 of one row.
 template <int CH>
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int w, int h, int stride, size_t frameStride,
-                                                uint8_t* __restrict__ pyr, size_t pyrFrameBytes, int pitch0, int aligned4)
+                                                uint8_t* __restrict__ pyr, size_t pyrFrameBytes, int pitch0, int aligned4,
+                                                int* __restrict__ zeroA, int nA, int* __restrict__ zeroB, int nB)
 {
+    // first kernel of the pipeline: it also clears the FAST stage's counters (no separate memset launches)
+    {
+        const unsigned nthreads = gridDim.x * gridDim.y * gridDim.z * 256u;
+        const unsigned flat = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+        for (unsigned i = flat; i < (unsigned)nA; i += nthreads) zeroA[i] = 0;
+        for (unsigned i = flat; i < (unsigned)nB; i += nthreads) zeroB[i] = 0;
+    }
     const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - kPadX;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x0 >= w + kPadX || y >= h) return;
@@ -51,17 +59,17 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src,
 }
 
 void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
-                      uint8_t* pyr, size_t pyrFrameBytes, int pitch0, hipStream_t s)
+                      uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s)
 {
     dim3 grid((w + 2 * kPadX + 255) / 256, (h + 3) / 4, batch);
     const int aligned4 = ((uintptr_t)src % 4 == 0) && (stride % 4 == 0) && (frameStride % 4 == 0);
-    hipLaunchKernelGGL(k_level0<1>, grid, dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, aligned4);
+    hipLaunchKernelGGL(k_level0<1>, grid, dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, aligned4, zeroA, nA, zeroB, nB);
 }
 void launch_rgb2gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
-                     uint8_t* pyr, size_t pyrFrameBytes, int pitch0, hipStream_t s)
+                     uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s)
 {
     dim3 grid((w + 2 * kPadX + 255) / 256, (h + 3) / 4, batch);
-    hipLaunchKernelGGL(k_level0<3>, grid, dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, 0);
+    hipLaunchKernelGGL(k_level0<3>, grid, dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, 0, zeroA, nA, zeroB, nB);
 }
 
 // ---------------------------------------------------------------------------
@@ -581,7 +589,8 @@ __device__ __forceinline__ void sincos_canonical(float xf, float& s, float& c)
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                   size_t pyrFrameBytes, KLevels kl, const uint2* __restrict__ sel,
                                                   const int* __restrict__ selCount, int selPerFrame, int cap,
-                                                  ssvio_keypoint* __restrict__ kpOut, uint8_t* __restrict__ desc, int* __restrict__ kpCount)
+                                                  ssvio_keypoint* __restrict__ kpOut, uint8_t* __restrict__ desc, int* __restrict__ kpCount,
+                                                  int* __restrict__ kpCountHost)
 {
     const int frame = blockIdx.y, lane = threadIdx.x & 63;
     const int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         if (l < kl.nlevels && k >= total + c) { level = l + 1; before = total + c; }
         total += c;
     }
-    if (k == 0 && lane == 0) kpCount[frame] = total;
+    if (k == 0 && lane == 0) { kpCount[frame] = total; kpCountHost[frame] = total; }   // second copy lands in pinned host memory
     if (k >= total) return;                       // wave-uniform
     const KLevel& L = kl.lv[level];
     const uint2 in = sel[(size_t)frame * selPerFrame + L.selBase + (k - before)];
@@ -653,10 +662,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
 
 void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl,
                      const uint2* sel, const int* selCount, int selPerFrame, int cap, ssvio_keypoint* kpOut, uint8_t* desc,
-                     int* kpCount, int batch, hipStream_t s)
+                     int* kpCount, int* kpCountHost, int batch, hipStream_t s)
 {
     hipLaunchKernelGGL(k_describe, dim3((cap + 3) / 4, batch), dim3(256), 0, s, pyr, blur, pyrFrameBytes, kl, sel, selCount, selPerFrame,
-                       cap, kpOut, desc, kpCount);
+                       cap, kpOut, desc, kpCount, kpCountHost);
 }
 
 }  // namespace ssvio

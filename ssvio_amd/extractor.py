@@ -80,12 +80,22 @@ class ORBextractor:
         self._last = (B, W, H)
         return kps, desc, n
 
-    def extract_batch_dev(self, d_imgs, batch, width, height, channels=1, stride=None, frame_stride=None):
-        """frames already in HBM (torch uint8 tensor or raw device pointer); results stay on the device"""
+    def extract_batch_dev(self, d_imgs, batch, width, height, channels=1, stride=None, frame_stride=None, wait=True):
+        """frames already in HBM (torch uint8 tensor or raw device pointer); results stay on the device.
+        wait=False only enqueues the work on the handle's stream (pipelined form, see sync())"""
         stride = stride or width * channels
         frame_stride = frame_stride or stride * height
-        L.check(L.lib().ssvio_orb_extract_batch_dev(self._h, L.ptr(d_imgs), batch, channels, width, height, stride, frame_stride))
+        fn = L.lib().ssvio_orb_extract_batch_dev if wait else L.lib().ssvio_orb_extract_batch_dev_async
+        L.check(fn(self._h, L.ptr(d_imgs), batch, channels, width, height, stride, frame_stride))
         self._last = (batch, width, height)
+
+    def sync(self): L.check(L.lib().ssvio_orb_sync(self._h))
+    def profile_only(self, kernel): L.check(L.lib().ssvio_orb_profile_only(self._h, kernel.encode() if kernel else None))
+
+    def get_stream(self):
+        s = C.c_void_p()
+        L.check(L.lib().ssvio_orb_get_stream(self._h, C.byref(s)))
+        return s.value
 
     def device_results(self):
         kp, de, n, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()

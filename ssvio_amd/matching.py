@@ -88,4 +88,5 @@ class FeatureMatching:
 
     def set_profiling(self, on): L.check(L.lib().ssvio_matcher_set_profiling(self._h, int(on)))
     def kernel_times(self): return L.kernel_times(L.lib().ssvio_matcher_kernel_times, self._h)
+    def profile_only(self, kernel): L.check(L.lib().ssvio_matcher_profile_only(self._h, kernel.encode() if kernel else None))
     def set_stream(self, stream): L.check(L.lib().ssvio_matcher_set_stream(self._h, L.ptr(stream)))

@@ -102,6 +102,40 @@ def test_batch_equals_singles_and_stream(mods):
     g.close()
 
 
+def test_pipelined_extract_and_match_on_one_stream(mods):
+    """ssvio_orb_extract_batch_dev_async + a matcher bound to the extractor's stream: several steps are enqueued with no
+    host wait in between; what is fetched afterwards equals the waiting calls' results and the oracle's matches"""
+    import torch
+    from ssvio_amd import _lib as L
+    S, synth, O = mods
+    B = 4
+    streams = [synth.frame_stream(40 + i, B) for i in range(3)]
+    g = S.ORBextractor(1000, 1.2, 8, 20, 7); fm = S.FeatureMatching(None, {})
+    fm.set_stream(g.get_stream())
+    pairs = np.array([[f, (f - 1) % B] for f in range(B)], np.int32)
+    d = [torch.from_numpy(fr).cuda() for fr in streams]
+    for i in range(3):                                   # three steps in flight; the last one's results stay
+        g.extract_batch_dev(d[i], B, 640, 480, wait=False)
+        _, d_desc, d_n, cap = g.device_results()
+        fm.match_batch_dev(d_desc, cap, cap, d_n, pairs, L.MODE_BRUTEFORCE)
+    kps, desc, n = g.fetch_results(B)                    # waits by itself
+    out, nm = fm.fetch_batch()
+    c = O.Extractor(1000, 1.2, 8, 20, 7)
+    ref = [c.extract(streams[2][f]) for f in range(B)]
+    for f in range(B):
+        assert n[f] == len(ref[f][0])
+        assert np.array_equal(kps[f, :n[f]].view(np.uint8), ref[f][0].view(np.uint8))
+        assert np.array_equal(desc[f, :n[f]], ref[f][1])
+    for p, (a, b) in enumerate(pairs):
+        want = O.match_bruteforce(ref[a][1], ref[b][1])
+        assert nm[p] == len(want)
+        assert np.array_equal(out[p, :nm[p]].view(np.uint8), want.view(np.uint8))
+    # the waiting form on the same handle afterwards
+    g.extract_batch_dev(d[0], B, 640, 480)
+    assert np.array_equal(g.last_counts(B), [len(c.extract(streams[0][f])[0]) for f in range(B)])
+    g.close(); fm.close()
+
+
 def test_low_texture_min_threshold_fallback(mods):
     """cells whose FAST(20) list is empty are retried at 7 (src/Feature.cpp:875-879)"""
     S, synth, O = mods
