@@ -586,14 +586,42 @@ __device__ __forceinline__ void sincos_canonical(float xf, float& s, float& c)
     s = (float)so; c = (float)co;
 }
 
+// byte masks of the IC patch rows (src/Feature.cpp:84-113 variant of SURVEY App. A4): row v = r - 14 keeps the
+// pixels u in [-d, d) with d = umax[|v|] (row 0: [-15, 16)); byte j of the 32-byte row window is pixel u = j - 16
+struct IcRowMasks { uint32_t m[29][8]; };
+constexpr IcRowMasks make_ic_masks()
+{
+    constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    IcRowMasks t{};
+    for (int r = 0; r < 29; ++r) {
+        const int v = r - 14, av = v < 0 ? -v : v, d = umax[av];
+        const int lo = 16 - d, hi = v == 0 ? 32 : 16 + d;
+        for (int j = 0; j < 32; ++j)
+            if (j >= lo && j < hi) t.m[r][j >> 2] |= 0xFFu << (8 * (j & 3));
+    }
+    return t;
+}
+__constant__ IcRowMasks c_icmask = make_ic_masks();
+
+__device__ __forceinline__ int half_sum(int v)          // sum over the 32 lanes of the lane's half-wave
+{
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// orientation + descriptor + final KeyPoint: TWO keypoints per wave (one per 32-lane half), so that the per-keypoint
+// scalar work (level lookup, fastAtan2, sin/cos) is issued once for both.
+//   moments: lane r < 29 of the half takes patch row v = r - 14 as 8 realigned dwords, masked, summed with v_dot4
+//   descriptor: lane takes tests sl, sl+32, ... (8 of the 256); the ballot's low / high word is the half's result
 __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                   size_t pyrFrameBytes, KLevels kl, const uint2* __restrict__ sel,
                                                   const int* __restrict__ selCount, int selPerFrame, int cap,
                                                   ssvio_keypoint* __restrict__ kpOut, uint8_t* __restrict__ desc, int* __restrict__ kpCount,
                                                   int* __restrict__ kpCountHost)
 {
-    const int frame = blockIdx.y, lane = threadIdx.x & 63;
-    const int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int frame = blockIdx.y, lane = threadIdx.x & 63, sl = lane & 31, half = lane >> 5;
+    const int k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
     // keypoint k of the frame in level-major order (src/Feature.cpp:537-567): locate its level list
     const int* sc = selCount + frame * kMaxLevels;
     int level = 0, before = 0, total = 0;
@@ -603,53 +631,64 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         if (l < kl.nlevels && k >= total + c) { level = l + 1; before = total + c; }
         total += c;
     }
-    if (k == 0 && lane == 0) { kpCount[frame] = total; kpCountHost[frame] = total; }   // second copy lands in pinned host memory
-    if (k >= total) return;                       // wave-uniform
+    if (blockIdx.x == 0 && threadIdx.x == 0) { kpCount[frame] = total; kpCountHost[frame] = total; }   // second copy lands in pinned host memory
+    if (__builtin_amdgcn_readfirstlane(k) >= total) return;        // the lower half's keypoint is the smaller index
+    const bool live = k < total;
+    if (!live) level = 0;
     const KLevel& L = kl.lv[level];
-    const uint2 in = sel[(size_t)frame * selPerFrame + L.selBase + (k - before)];
-    const int x = in.x & 0xFFFF, y = in.x >> 16, resp = (in.y >> 8) & 0xFF;
+    int x = kEdge, y = kEdge, resp = 0;
+    if (live) {
+        const uint2 in = sel[(size_t)frame * selPerFrame + L.selBase + (k - before)];
+        x = in.x & 0xFFFF; y = in.x >> 16; resp = (in.y >> 8) & 0xFF;
+    }
     const int pitch = L.pitch;
-    const uint8_t* center = pyr + (size_t)frame * pyrFrameBytes + L.offset + (size_t)y * pitch + x;
-    // moments: lane -> row v = lane-14 (29 rows -14..14, row 0 spans u=-15..15, others u=-d..d-1); lanes 32..63 take the
-    // upper half of each row's columns to balance
+    const size_t centerOff = (size_t)frame * pyrFrameBytes + L.offset + (size_t)y * pitch + x;
     int m01 = 0, m10 = 0;
     {
-        const int row = lane & 31, half = lane >> 5;
-        if (row < 29) {
-            const int v = row - 14, av = v < 0 ? -v : v;
-            const int d = c_umax[av];
-            const int u0 = -d, u1 = (v == 0) ? d + 1 : d;          // [u0, u1)
-            const int mid = (u0 + u1) >> 1;
-            const int ub = half ? mid : u0, ue = half ? u1 : mid;
-            const uint8_t* rp = center + v * pitch;
-            int sv = 0, su = 0;
-            for (int u = ub; u < ue; ++u) { const int val = rp[u]; sv += val; su += u * val; }
-            m10 = su; m01 = v * sv;
+        const int r = min(sl, 28), v = r - 14;
+        const uint8_t* rp = pyr + centerOff + v * pitch - 16;             // pixel u = -16 of the row
+        const unsigned sh = (unsigned)(uintptr_t)rp & 3u;
+        const uint32_t* ap = (const uint32_t*)(rp - sh);
+        uint32_t w[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) w[i] = ap[i];
+        const uint4 ma = ((const uint4*)c_icmask.m[r])[0], mb = ((const uint4*)c_icmask.m[r])[1];
+        const uint32_t mk[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+        unsigned sv = 0, sj = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t px = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh) & mk[i];      // pixels u = 4i-16 .. 4i-13
+            sv = __builtin_amdgcn_udot4(px, 0x01010101u, sv, false);
+            sj = __builtin_amdgcn_udot4(px, 0x03020100u + 0x04040404u * i, sj, false);       // weights j = u + 16
         }
+        if (sl < 29) { m10 = (int)sj - 16 * (int)sv; m01 = v * (int)sv; }
     }
-    m01 = wave_sum(m01); m10 = wave_sum(m10);
+    m01 = half_sum(m01); m10 = half_sum(m10);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // descriptor
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
     float a, b;
     sincos_canonical(ang, b, a);
-    const uint8_t* bc = blur + (size_t)frame * pyrFrameBytes + L.offset + (size_t)y * pitch + x;
-    unsigned long long words[4];
+    const uint8_t* bc = blur + centerOff;
+    uint32_t myword = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int8_t* p = c_pattern + (size_t)(j * 64 + lane) * 4;
+    for (int j = 0; j < 8; ++j) {
+        const int8_t* p = c_pattern + (size_t)(j * 32 + sl) * 4;
         const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
         const int t0 = bc[r0 * pitch + q0], t1 = bc[r1 * pitch + q1];
-        words[j] = __ballot(t0 < t1);
+        const unsigned long long bal = __ballot(t0 < t1);
+        const uint32_t mine = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;       // tests 32j .. 32j+31 of this half's keypoint
+        if (sl == j) myword = mine;
     }
+    if (!live) return;
     const size_t o = (size_t)frame * cap + k;
-    if (lane < 4) ((unsigned long long*)(desc + o * 32))[lane] = words[lane];
-    if (lane == 0) {
+    if (sl < 8) ((uint32_t*)(desc + o * 32))[sl] = myword;
+    if (sl == 0) {
         ssvio_keypoint kp;
         const float scale = L.scale;
         kp.x = level ? __fmul_rn((float)x, scale) : (float)x;       // src/Feature.cpp:557-563
@@ -664,7 +703,7 @@ void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameByt
                      const uint2* sel, const int* selCount, int selPerFrame, int cap, ssvio_keypoint* kpOut, uint8_t* desc,
                      int* kpCount, int* kpCountHost, int batch, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_describe, dim3((cap + 3) / 4, batch), dim3(256), 0, s, pyr, blur, pyrFrameBytes, kl, sel, selCount, selPerFrame,
+    hipLaunchKernelGGL(k_describe, dim3((cap + 7) / 8, batch), dim3(256), 0, s, pyr, blur, pyrFrameBytes, kl, sel, selCount, selPerFrame,
                        cap, kpOut, desc, kpCount, kpCountHost);
 }
 
