@@ -186,7 +186,7 @@ static void fill_klevels(const PyramidGeom& g, KLevels& k)
         KLevel& K = k.lv[l];
         K.w = L.w; K.h = L.h; K.pitch = L.pitch; K.offset = L.offset;
         K.nCols = L.nCols; K.nRows = L.nRows; K.wCell = L.wCell; K.hCell = L.hCell; K.cellBase = L.cellBase;
-        K.fastTileBase = L.fastTileBase; K.fastTilesX = L.fastTilesX;
+        K.fastTileBase = L.fastTileBase; K.fastTilesX = L.fastTilesX; K.fastTileBaseT = L.fastTileBaseT;
         K.blurStripBase = L.blurStripBase; K.blurStripsX = L.blurStripsX; K.blurIters = L.blurIters;
         K.quota = L.quota; K.kpSize = L.kpSize; K.scale = L.scale;
         K.rawBase = (unsigned)L.slotBase; K.rawCap = (unsigned)L.slotCap * L.nCols * L.nRows;
@@ -195,7 +195,7 @@ static void fill_klevels(const PyramidGeom& g, KLevels& k)
         for (int i = 0; i < 5; ++i) K.rootX[i] = L.rootX[i];
     }
     KLevel& E = k.lv[g.nlevels];
-    E.cellBase = g.cellsPerFrame; E.fastTileBase = g.fastTilesPerFrame; E.blurStripBase = g.blurStripsPerFrame;
+    E.cellBase = g.cellsPerFrame; E.fastTileBase = g.fastTilesPerFrame; E.fastTileBaseT = g.fastTilesPerFrameT; E.blurStripBase = g.blurStripsPerFrame;
     E.rawBase = (unsigned)g.slotsPerFrame;
 }
 
@@ -356,7 +356,9 @@ static int orb_run(ssvio_orb* h, int batch, bool wait = true)
     }
     {
         ProfScope p(h->prof, "k_fast", s);
-        launch_fast(h->d_pyr, g.frameBytes, h->kl, g.fastTilesPerFrame, g.cellsPerFrame, g.slotsPerFrame, h->tab.iniTh, h->tab.minTh,
+        // tall tiles halve the per-tile fixed work; short ones give a small batch enough workgroups to fill the chip
+        const bool tall = (long)g.fastTilesPerFrameT * batch >= 2048;
+        launch_fast(h->d_pyr, g.frameBytes, h->kl, tall ? g.fastTilesPerFrameT : g.fastTilesPerFrame, tall, g.cellsPerFrame, g.slotsPerFrame, h->tab.iniTh, h->tab.minTh,
                     h->d_raw, h->d_rawCount, h->d_cellIni, batch, s);
     }
     // the blur depends on the pyramid only: it runs on the side stream beside k_quadtree (one workgroup per frame-level,

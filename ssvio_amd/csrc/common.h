@@ -41,7 +41,8 @@ struct LevelGeom {
     int quota;                // mnFeaturesPerLevel
     float scale;              // mvScaleFactor
     int kpSize;               // (int)(15*scale)
-    int fastTileBase, fastTilesX, fastTilesY;   // k_fast_score tiles (64 x 32 px)
+    int fastTileBase, fastTilesX, fastTilesY;   // k_fast tiles (64 x 32 px)
+    int fastTileBaseT, fastTilesYT;             // ... and the tall form (64 x 64 px) used for large batches
     int blurStripBase, blurStripsX, blurStripsY, blurIters;   // k_blur strips: 120 px wide, 7*blurIters-6 rows tall
     size_t tabOffset;         // offset (in shorts) of this level's resize tables
 };
@@ -54,7 +55,7 @@ struct PyramidGeom {
     int cellsPerFrame = 0;
     size_t slotsPerFrame = 0;
     int blurStripsPerFrame = 0;
-    int fastTilesPerFrame = 0;
+    int fastTilesPerFrame = 0, fastTilesPerFrameT = 0;
     int maxQuotaSum = 0;
 };
 
@@ -64,7 +65,7 @@ struct KLevel {
     int w, h, pitch;
     int nCols, nRows, wCell, hCell;
     int cellBase;
-    int fastTileBase, fastTilesX;
+    int fastTileBase, fastTilesX, fastTileBaseT;
     int blurStripBase, blurStripsX, blurIters;
     int quota, kpSize;
     float scale;
@@ -73,7 +74,6 @@ struct KLevel {
     int selBase;                      // this level's region of the selected-keypoint list of a frame
     int nIni; float hX; int rootX[5]; // quadtree roots (src/Feature.cpp:574-593)
     int wCellMagic, hCellMagic;       // ceil(2^20 / cell size): (n * magic) >> 20 == n / cell for n < 4096
-    int pad0;
 };
 struct KLevels {
     int nlevels;
@@ -144,7 +144,7 @@ void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int le
                    size_t xTabOff, size_t yTabOff, size_t quadTabOff, int mode /*0 generic, 1 quad, 2 area 2x2*/, int rows, int batch, hipStream_t s);
 // FAST: appends {key, val} per NMS survivor to the level's raw list; key = flags<<30 | cell<<12 | iy<<6 | ix
 // (flags bit0: passes at iniTh, bit1: at minTh), val = x | y<<12 | score<<24 relative to minBorder
-void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, int cellsPerFrame, size_t rawPerFrame,
+void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame /* of the chosen form */, bool tall, int cellsPerFrame, size_t rawPerFrame,
                  int iniTh, int minTh, uint2* raw, int* rawCount, int* cellIni, int batch, hipStream_t s);
 int  launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipStream_t s);
 void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int stripsPerFrame, int batch, hipStream_t s);

@@ -57,7 +57,7 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
 {
     g = PyramidGeom();
     g.nlevels = t.nlevels; g.width = width; g.height = height;
-    size_t off = 0, slot = 0; int cell = 0, tiles = 0, ftiles = 0;
+    size_t off = 0, slot = 0; int cell = 0, tiles = 0, ftiles = 0, ftilesT = 0;
     for (int l = 0; l < t.nlevels; ++l) {
         LevelGeom& L = g.lv[l];
         L.w = round_half_even((float)width * t.invScale[l]);
@@ -100,10 +100,12 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
         L.blurStripBase = tiles; tiles += L.blurStripsX * L.blurStripsY;
         L.fastTilesX = (L.w + 63) / 64; L.fastTilesY = (L.h + 31) / 32;
         L.fastTileBase = ftiles; ftiles += L.fastTilesX * L.fastTilesY;
+        L.fastTilesYT = (L.h + 63) / 64;
+        L.fastTileBaseT = ftilesT; ftilesT += L.fastTilesX * L.fastTilesYT;
         g.maxQuotaSum += L.quota;
     }
     g.frameBytes = off + 256;
-    g.cellsPerFrame = cell; g.slotsPerFrame = slot; g.blurStripsPerFrame = tiles; g.fastTilesPerFrame = ftiles;
+    g.cellsPerFrame = cell; g.slotsPerFrame = slot; g.blurStripsPerFrame = tiles; g.fastTilesPerFrame = ftiles; g.fastTilesPerFrameT = ftilesT;
     return SSVIO_OK;
 }
 

@@ -203,10 +203,9 @@ void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int le
 // Survivors are appended (unordered) to the level's raw list with both flags (iniTh / minTh) and their
 // position in the reference's append order as key; cellIni[cell] is raised when a cell has an iniTh
 // survivor, which is what decides the minTh retry of src/Feature.cpp:875 (resolved by the consumer).
-constexpr int kFtW = 64, kFtH = 32;          // output tile
+constexpr int kFtW = 64;                     // output tile width; the height FH is 32 or 64 (template parameter)
 constexpr int kFtPitch = 72;                 // LDS row bytes: x0-4 .. x0+67
-constexpr int kFtRows = kFtH + 8;            // input rows y0-4 .. y0+35
-constexpr int kScRows = kFtH + 2;            // score rows y0-1 .. y0+32 (same column layout as the input tile)
+// input rows y0-4 .. y0+FH+3 (FH + 8), score rows y0-1 .. y0+FH (FH + 2, same column layout as the input tile)
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 
@@ -227,47 +226,51 @@ __device__ __forceinline__ short2v arc9_maxmin_pk(const short2v (&p)[16])
     return r;
 }
 
+template <bool TALL>
 __device__ __forceinline__ int find_fast_level(const KLevels& kl, int id)
 {
     int level = 0;
 #pragma unroll
-    for (int l = 1; l < kMaxLevels; ++l) level += (l < kl.nlevels && id >= kl.lv[l].fastTileBase) ? 1 : 0;
+    for (int l = 1; l < kMaxLevels; ++l) level += (l < kl.nlevels && id >= (TALL ? kl.lv[l].fastTileBaseT : kl.lv[l].fastTileBase)) ? 1 : 0;
     return level;
 }
 
+template <int FH>
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, size_t pyrFrameBytes, KLevels kl, int cellsPerFrame,
                                               size_t rawPerFrame, int iniTh, int minTh, uint2* __restrict__ raw,
                                               int* __restrict__ rawCount, int* __restrict__ cellIni)
 {
+    constexpr int kFtH = FH, kFtRows = FH + 8, kScRows = FH + 2;
+    constexpr int kLoadPasses = (kFtRows + 13) / 14, kScanPasses = (kScRows + 13) / 14;      // rows r0, r0+14, ... per thread
     __shared__ __attribute__((aligned(16))) uint32_t tile[kFtRows * kFtPitch / 4];
     __shared__ __attribute__((aligned(16))) uint32_t sc[kScRows * kFtPitch / 4];
     __shared__ uint16_t queue[kScRows * kFtPitch];
     __shared__ uint2 outbuf[kFtW * kFtH / 4];            // NMS survivors of one tile: no two are 8-adjacent within a cell
     __shared__ int qn, on, obase;
     const int tid = threadIdx.x, frame = blockIdx.y;
-    const int level = find_fast_level(kl, blockIdx.x);
+    const int level = find_fast_level<FH == 64>(kl, blockIdx.x);
     const KLevel& L = kl.lv[level];
-    const int t = blockIdx.x - L.fastTileBase;
+    const int t = blockIdx.x - (FH == 64 ? L.fastTileBaseT : L.fastTileBase);
     const int tyi = t / L.fastTilesX, txi = t - tyi * L.fastTilesX;
     const int w = L.w, h = L.h, pitch = L.pitch;
     const int x0 = txi * kFtW, y0 = tyi * kFtH;
     const int tLow = min(iniTh, minTh);
     const uint8_t* img = pyr + (size_t)frame * pyrFrameBytes + L.offset;
     const int xMaxLoad = (w + 56) & ~3;                    // last dword that is still inside the row's slack
-    // thread -> (row r0 = tid / 18, dword column c = tid % 18) once; rows r0, r0+14, r0+28 per pass (252 threads busy)
+    // thread -> (row r0 = tid / 18, dword column c = tid % 18) once; rows r0, r0+14, r0+28, ... per pass (252 threads busy)
     const int r0 = (int)(__umul24(tid, 3641u) >> 16), c0 = tid - r0 * (kFtPitch / 4);
     const bool lane252 = tid < 252;
     {
-        uint32_t ld[3];
+        uint32_t ld[kLoadPasses];
         const int xoff = min(x0 - 4 + 4 * c0, xMaxLoad);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < kLoadPasses; ++k) {
             const int r = r0 + 14 * k;
             const int yy = min(max(y0 - 4 + r, 0), h - 1);
             ld[k] = (lane252 && r < kFtRows) ? *(const uint32_t*)(img + (size_t)yy * pitch + xoff) : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < kLoadPasses; ++k) {
             const int r = r0 + 14 * k;
             if (lane252 && r < kFtRows) tile[r * (kFtPitch / 4) + c0] = ld[k];
             if (lane252 && r < kScRows) sc[r * (kFtPitch / 4) + c0] = 0;
@@ -279,13 +282,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     // phase 1, packed: a 9-arc always contains two ADJACENT compass pixels (ring 0,4,8,12); "some adjacent
     // compass pair in one class" == (down|up) & (left|right) per class.  Two pixels per packed-i16 register.
     // Domain: score rows y0-1 .. y0+32 (r = 0..33), quad columns x0-4 .. x0+67 (pixels outside x0-1 .. x0+64 dropped).
-    unsigned flags = 0;                                     // bit (4k+i): pixel i of this thread's quad k survives
+    unsigned flags = 0;                                     // bit (4k+i): pixel i of this thread's quad k survives (kScanPasses <= 5)
     const short2v T2 = short2v{(short)tLow, (short)tLow};
     // tile (with its 1-px halo) entirely inside the tested region [19, w-20] x [19, h-20]?
     const bool allValid = x0 - 1 >= kEdge && x0 + kFtW <= w - kEdge - 1 && y0 - 1 >= kEdge && y0 + kFtH <= h - kEdge - 1;
     const int qc = c0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < kScanPasses; ++k) {
         const int r = min(r0 + 14 * k, kScRows - 1);
         const bool qlive = lane252 && r0 + 14 * k < kScRows;
         const int rowC = (r + 3) * (kFtPitch / 4);          // input row of score row r
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     for (int q = tid; q < nq; q += 256) {
         const int p = queue[q];
         const int s = sb[p];
-        const int r = (int)(__umul24(p, 1821u) >> 17), cidx = p - r * kFtPitch;        // p / 72 for p < 2600
+        const int r = (int)(__umul24(p, 14564u) >> 20), cidx = p - r * kFtPitch;       // p / 72 for p < 33000
         const int lx = cidx - 4, ly = r - 1;
         if (s == 0 || lx < 0 || lx >= kFtW || ly < 0 || ly >= kFtH) continue;
         const int x = x0 + lx, y = y0 + ly;
@@ -401,11 +404,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     for (int i = tid; i < no; i += 256) if ((unsigned)(obase + i) < L.rawCap) dst[obase + i] = outbuf[i];
 }
 
-void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, int cellsPerFrame, size_t rawPerFrame,
+void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, bool tall, int cellsPerFrame, size_t rawPerFrame,
                  int iniTh, int minTh, uint2* raw, int* rawCount, int* cellIni, int batch, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_fast, dim3(tilesPerFrame, batch), dim3(256), 0, s, pyr, pyrFrameBytes, kl, cellsPerFrame, rawPerFrame,
-                       iniTh, minTh, raw, rawCount, cellIni);
+    if (tall) hipLaunchKernelGGL(k_fast<64>, dim3(tilesPerFrame, batch), dim3(256), 0, s, pyr, pyrFrameBytes, kl, cellsPerFrame, rawPerFrame,
+                                 iniTh, minTh, raw, rawCount, cellIni);
+    else hipLaunchKernelGGL(k_fast<32>, dim3(tilesPerFrame, batch), dim3(256), 0, s, pyr, pyrFrameBytes, kl, cellsPerFrame, rawPerFrame,
+                            iniTh, minTh, raw, rawCount, cellIni);
 }
 
 // ---------------------------------------------------------------------------
@@ -520,9 +525,18 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const 
 
 // ---------------------------------------------------------------------------
 // IC_Angle (src/Feature.cpp:84-113) + steered BRIEF (src/Feature.cpp:446-482): one wave per keypoint.
-__constant__ int8_t c_pattern[1024] = {
+constexpr int8_t kPatternI8[1024] = {
 #include "orb_pattern.inc"
 };
+// the same table as floats, one 16-byte {x0, y0, x1, y1} record per test (the kernel multiplies them by sin/cos)
+struct PatternF { float v[1024]; };
+constexpr PatternF make_pattern_f()
+{
+    PatternF t{};
+    for (int i = 0; i < 1024; ++i) t.v[i] = (float)kPatternI8[i];
+    return t;
+}
+__constant__ __attribute__((aligned(16))) PatternF c_patf = make_pattern_f();
 // umax of src/Feature.cpp:425-443 for HALF_PATCH_SIZE 15
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
@@ -588,6 +602,10 @@ __device__ __forceinline__ void sincos_canonical(float xf, float& s, float& c)
 
 // byte masks of the IC patch rows (src/Feature.cpp:84-113 variant of SURVEY App. A4): row v = r - 14 keeps the
 // pixels u in [-d, d) with d = umax[|v|] (row 0: [-15, 16)); byte j of the 32-byte row window is pixel u = j - 16
+constexpr int kDescThreads = 512;             // 8 waves = 16 keypoints per workgroup
+constexpr int kDescR = 18;                   // |rotated pattern coordinate| <= round(13 * sqrt 2) = 18
+constexpr int kDescRows = 2 * kDescR + 1;     // 37 rows
+constexpr int kDescDw = 10;                   // 37 columns + up to 3 bytes of alignment = 40 bytes per staged row
 struct IcRowMasks { uint32_t m[29][8]; };
 constexpr IcRowMasks make_ic_masks()
 {
@@ -614,22 +632,31 @@ __device__ __forceinline__ int half_sum(int v)          // sum over the 32 lanes
 // scalar work (level lookup, fastAtan2, sin/cos) is issued once for both.
 //   moments: lane r < 29 of the half takes patch row v = r - 14 as 8 realigned dwords, masked, summed with v_dot4
 //   descriptor: lane takes tests sl, sl+32, ... (8 of the 256); the ballot's low / high word is the half's result
-__global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+__global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                   size_t pyrFrameBytes, KLevels kl, const uint2* __restrict__ sel,
                                                   const int* __restrict__ selCount, int selPerFrame, int cap,
                                                   ssvio_keypoint* __restrict__ kpOut, uint8_t* __restrict__ desc, int* __restrict__ kpCount,
                                                   int* __restrict__ kpCountHost)
 {
     const int frame = blockIdx.y, lane = threadIdx.x & 63, sl = lane & 31, half = lane >> 5;
-    const int k = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
-    // keypoint k of the frame in level-major order (src/Feature.cpp:537-567): locate its level list
-    const int* sc = selCount + frame * kMaxLevels;
-    int level = 0, before = 0, total = 0;
+    const int k = (blockIdx.x * (kDescThreads / 64) + (threadIdx.x >> 6)) * 2 + half;
+    // the 4-KB test pattern is fetched once per workgroup; every wave then reads its records from LDS
+    __shared__ float4 spat[256];
+    if (threadIdx.x < 256) spat[threadIdx.x] = ((const float4*)c_patf.v)[threadIdx.x];
+    __syncthreads();
+    // keypoint k of the frame in level-major order (src/Feature.cpp:537-567): locate its level list.  Lane l < 16 of each
+    // half holds the inclusive prefix of the level counts; the level is the number of prefixes <= k.
+    int level, before, total;
+    {
+        const int l = sl & 15;
+        int incl = l < kl.nlevels ? selCount[frame * kMaxLevels + l] : 0;
 #pragma unroll
-    for (int l = 0; l < kMaxLevels; ++l) {
-        const int c = l < kl.nlevels ? sc[l] : 0;
-        if (l < kl.nlevels && k >= total + c) { level = l + 1; before = total + c; }
-        total += c;
+        for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(incl, o, 16); if (l >= o) incl += t; }
+        total = __shfl(incl, 15, 16);
+        const unsigned long long vote = __ballot(sl < kl.nlevels && incl <= k);
+        level = __popc(half ? (uint32_t)(vote >> 32) : (uint32_t)vote);
+        before = __shfl(incl, max(level - 1, 0), 16);                 // lanes 0..15 of the same half
+        if (level == 0) before = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { kpCount[frame] = total; kpCountHost[frame] = total; }   // second copy lands in pinned host memory
     if (__builtin_amdgcn_readfirstlane(k) >= total) return;        // the lower half's keypoint is the smaller index
@@ -642,16 +669,38 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         x = in.x & 0xFFFF; y = in.x >> 16; resp = (in.y >> 8) & 0xFF;
     }
     const int pitch = L.pitch;
-    const size_t centerOff = (size_t)frame * pyrFrameBytes + L.offset + (size_t)y * pitch + x;
+    const uint8_t* pyrF = pyr + (size_t)frame * pyrFrameBytes;           // wave-uniform bases, 32-bit lane offsets
+    const uint8_t* blurF = blur + (size_t)frame * pyrFrameBytes;
+    const uint32_t centerOff = (uint32_t)L.offset + (uint32_t)(__mul24(y, pitch) + x);
+    // Both patches are fetched with lane -> (row, dword) so that one load instruction touches a handful of cache lines
+    // (a lane-per-row or per-sample fetch touches up to 64 and the vector L1 serialises on lines), then pass through LDS:
+    // the intensity patch to turn into one row per lane, the blurred patch to be sampled at the 512 rotated positions.
+    __shared__ uint32_t patch[kDescThreads / 32][kDescRows * kDescDw];                      // one region per half-wave (keypoint)
+    uint32_t* lp = patch[(threadIdx.x >> 6) * 2 + half];
+    // level offsets and pitches are multiples of 64 and the buffers are 256-byte aligned: alignment shifts come from x alone
+    uint32_t ip = centerOff - 14 * pitch - 16;                              // intensity window: rows -14..14, pixels u = -16..
+    const unsigned sh = ip & 3u; ip -= sh;
+    uint32_t bp = centerOff - kDescR * pitch - kDescR;                      // blurred window: rows/cols -18..18
+    const unsigned shb = bp & 3u; bp -= shb;
+    uint32_t wi[9], wb[12];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const unsigned e = min(sl + 32u * t, 29u * 9u - 1u), r = e / 9u, i = e - 9u * r;
+        wi[t] = *(const uint32_t*)(pyrF + (ip + __umul24(r, (unsigned)pitch) + 4 * i));
+    }
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+        const unsigned e = min(sl + 32u * t, (unsigned)(kDescRows * kDescDw) - 1u), r = e / (unsigned)kDescDw, i = e - kDescDw * r;
+        wb[t] = *(const uint32_t*)(blurF + (bp + __umul24(r, (unsigned)pitch) + 4 * i));
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) if (sl + 32u * t < 29u * 9u) lp[sl + 32 * t] = wi[t];
     int m01 = 0, m10 = 0;
     {
         const int r = min(sl, 28), v = r - 14;
-        const uint8_t* rp = pyr + centerOff + v * pitch - 16;             // pixel u = -16 of the row
-        const unsigned sh = (unsigned)(uintptr_t)rp & 3u;
-        const uint32_t* ap = (const uint32_t*)(rp - sh);
         uint32_t w[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) w[i] = ap[i];
+        for (int i = 0; i < 9; ++i) w[i] = lp[r * 9 + i];                   // stride 9 dwords: conflict-free
         const uint4 ma = ((const uint4*)c_icmask.m[r])[0], mb = ((const uint4*)c_icmask.m[r])[1];
         const uint32_t mk[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
         unsigned sv = 0, sj = 0;
@@ -664,23 +713,26 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ py
         if (sl < 29) { m10 = (int)sj - 16 * (int)sv; m01 = v * (int)sv; }
     }
     m01 = half_sum(m01); m10 = half_sum(m10);
+    // the intensity rows have been consumed (LDS operations of a wave complete in order): reuse the region
+#pragma unroll
+    for (int t = 0; t < 12; ++t) if (sl + 32u * t < (unsigned)(kDescRows * kDescDw)) lp[sl + 32 * t] = wb[t];
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // descriptor
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
     float a, b;
     sincos_canonical(ang, b, a);
-    const uint8_t* bc = blur + centerOff;
+    const uint8_t* bc = (const uint8_t*)lp + kDescR * (kDescDw * 4) + kDescR + shb;           // the keypoint inside the staged window
     uint32_t myword = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int8_t* p = c_pattern + (size_t)(j * 32 + sl) * 4;
-        const float x0 = (float)p[0], y0 = (float)p[1], x1 = (float)p[2], y1 = (float)p[3];
+        const float4 pt = spat[j * 32 + sl];
+        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bc[r0 * pitch + q0], t1 = bc[r1 * pitch + q1];
+        const int t0 = bc[__mul24(r0, kDescDw * 4) + q0], t1 = bc[__mul24(r1, kDescDw * 4) + q1];
         const unsigned long long bal = __ballot(t0 < t1);
         const uint32_t mine = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;       // tests 32j .. 32j+31 of this half's keypoint
         if (sl == j) myword = mine;
@@ -703,7 +755,7 @@ void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameByt
                      const uint2* sel, const int* selCount, int selPerFrame, int cap, ssvio_keypoint* kpOut, uint8_t* desc,
                      int* kpCount, int* kpCountHost, int batch, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_describe, dim3((cap + 7) / 8, batch), dim3(256), 0, s, pyr, blur, pyrFrameBytes, kl, sel, selCount, selPerFrame,
+    hipLaunchKernelGGL(k_describe, dim3((cap + kDescThreads / 32 - 1) / (kDescThreads / 32), batch), dim3(kDescThreads), 0, s, pyr, blur, pyrFrameBytes, kl, sel, selCount, selPerFrame,
                        cap, kpOut, desc, kpCount, kpCountHost);
 }
 
