@@ -26,7 +26,11 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6e12 int lane-ops/s
+# VALU issue cost of one (query, train) descriptor pair in k_hamming_knn2, from the measured wave64 issue rates in
+# profiles/r1/ubench_valu_rate.txt (tools/ubench/valu_rate.hip on this chip): v_xor_b32 2.46 cycles per wave
+# instruction per SIMD, v_bcnt_u32_b32 / v_lshl_or_b32 / v_med3_u32 / v_min_u32 4.13
+MATCH_CYCLES_PER_PAIR = 8 * 2.46 + 11 * 4.13
+VALU_PEAK_PAIRS = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR      # 1024 SIMDs x 2.4 GHz x 64 lanes = 2.42e12 pairs/s
 
 
 def level_pixels(ex, w, h):
@@ -88,6 +92,7 @@ def main():
     ap.add_argument("--features", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="host waits for every step (latency mode)")
+    ap.add_argument("--streams", type=int, default=2, help="steps in flight: step i runs on handle pair i %% streams, each pair on its own HIP stream")
     ap.add_argument("--all-kernel-events", action="store_true", help="hipEvent pairs around every kernel in the timed region (slower)")
     args = ap.parse_args()
 
@@ -110,45 +115,72 @@ def main():
     B, W, H = args.batch, args.width, args.height
     frames = synth.frame_stream(1000 + rank, B, H, W)            # seeded, per-rank stream
     d_frames = torch.from_numpy(frames).to(dev)
-    ex = ssvio_amd.ORBextractor(args.features, 1.2, 8, 20, 7, device=dev.index)
-    fm = ssvio_amd.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6}, device=dev.index)
+    # S handle pairs, each pair (extractor + matcher) on its own HIP stream; step i runs on pair i % S, so that S steps
+    # are in flight and one step's low-occupancy kernels (quadtree, small pyramid levels) overlap another's
+    S = max(1, args.streams)
+    exs = [ssvio_amd.ORBextractor(args.features, 1.2, 8, 20, 7, device=dev.index) for _ in range(S)]
+    fms = [ssvio_amd.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6}, device=dev.index) for _ in range(S)]
+    ex, fm = exs[0], fms[0]
     pairs = np.array([[f, (f - 1) % B] for f in range(B)], np.int32)
-
-    # pipelined form (SURVEY.md §8d config 2 "sustained fps (pipelined)"): extractor and matcher enqueue on ONE
+    # pipelined form (SURVEY.md §8d config 2 "sustained fps (pipelined)"): extractor and matcher of a pair enqueue on ONE
     # stream and the host does not wait inside a step; --sync-steps restores one host wait per step
-    fm.set_stream(ex.get_stream())
+    for e, m in zip(exs, fms):
+        m.set_stream(e.get_stream())
+    nstep = [0]
+    inflight = [S]
 
     def step():
-        ex.extract_batch_dev(d_frames, B, W, H, wait=args.sync_steps)
-        d_kp, d_desc, d_n, cap = ex.device_results()
-        fm.match_batch_dev(d_desc, cap, cap, d_n, pairs, L.MODE_BRUTEFORCE)
+        e, m = exs[nstep[0] % inflight[0]], fms[nstep[0] % inflight[0]]
+        nstep[0] += 1
+        e.extract_batch_dev(d_frames, B, W, H, wait=args.sync_steps)
+        d_kp, d_desc, d_n, cap = e.device_results()
+        m.match_batch_dev(d_desc, cap, cap, d_n, pairs, L.MODE_BRUTEFORCE)
         if args.sync_steps:
-            fm.sync()
+            m.sync()
 
-    for _ in range(args.warmup):
+    def sync_all():
+        for e, m in zip(exs, fms):
+            m.sync(); e.sync()
+
+    def profiling(on, only_ex=None, only_fm=None):
+        for e, m in zip(exs, fms):
+            e.profile_only(only_ex); m.profile_only(only_fm)
+            e.set_profiling(on and (only_fm is None)); m.set_profiling(on and (only_ex is None))
+
+    def kernel_times():
+        tot = {}
+        for h in exs + fms:
+            for k, (ms, n) in h.kernel_times().items():
+                a, c = tot.get(k, (0.0, 0))
+                tot[k] = (a + ms, c + n)
+        return tot
+
+    for _ in range(max(args.warmup, S)):        # every pair allocates on its first step
         step()
-    fm.sync(); ex.sync()
-    # one more untimed step with event pairs around every kernel: finds the kernel with the largest share of GPU time
-    ex.set_profiling(True); fm.set_profiling(True)
+    sync_all()
+    # one more untimed step, alone on the GPU, with event pairs around every kernel: finds the kernel with the largest
+    # share of GPU time
+    profiling(True)
+    inflight[0] = 1
     step()
-    fm.sync(); ex.sync()
-    wt = dict(ex.kernel_times()); own_ex = set(wt); wt.update(fm.kernel_times())
+    sync_all()
+    inflight[0] = S
+    wt = kernel_times()
     dom = max(wt, key=lambda k: wt[k][0])
-    ex.set_profiling(False); fm.set_profiling(False)
+    dom_is_ex = dom in exs[0].kernel_times()
+    profiling(False)
     # timed region: only the dominant kernel is bracketed (two events per step); pairs around all ~18 launches
-    # cost ~0.13 ms per step on this stream, so the full table comes from a second pass of the same steps
+    # cost ~0.1 ms per step on this stream, so the full table comes from a second pass of the same steps
     if args.all_kernel_events:
-        ex.set_profiling(True); fm.set_profiling(True)
-    elif dom in own_ex:
-        ex.profile_only(dom); ex.set_profiling(True)
+        profiling(True)
     else:
-        fm.profile_only(dom); fm.set_profiling(True)
+        profiling(True, only_ex=dom if dom_is_ex else None, only_fm=None if dom_is_ex else dom)
     torch.cuda.synchronize()
     if dist: dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fm.sync(); ex.sync()                 # the library's stream is not torch's: wait for it, then for the device
+    sync_all()                           # the library's streams are not torch's: wait for them, then for the device
     torch.cuda.synchronize()
     if dist: dist.barrier()
     dt = time.perf_counter() - t0
@@ -163,16 +195,16 @@ def main():
         total_frames = B * args.steps
 
     # per-kernel GPU time over the timed region
-    times = dict(ex.kernel_times()); times.update(fm.kernel_times())
+    times = kernel_times()
     dom_ms, dom_launches = times[dom]
-    if not args.all_kernel_events:       # same steps again with the event pairs around every kernel, for the table
-        ex.profile_only(None); fm.profile_only(None)
-        ex.set_profiling(True); fm.set_profiling(True)
-        for _ in range(args.steps):
-            step()
-        fm.sync(); ex.sync()
-        times = dict(ex.kernel_times()); times.update(fm.kernel_times())
-    ex.set_profiling(False); fm.set_profiling(False)
+    # the same steps again, one in flight, with event pairs around every kernel: the per-kernel table (exclusive times)
+    profiling(False); profiling(True)
+    inflight[0] = 1
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    times = kernel_times()
+    profiling(False)
     counts = ex.last_counts(B)
     _, nmatch = fm.fetch_batch(counts_only=True)
     px = level_pixels(ex, W, H)
@@ -188,14 +220,17 @@ def main():
     achieved = dom_bytes / dom_avg_s / 1e9
     roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "avg_launch_us": round(dom_avg_s * 1e6, 2), "alg_bytes_per_launch": int(dom_bytes)}
+            "avg_launch_us": round(dom_avg_s * 1e6, 2), "alg_bytes_per_launch": int(dom_bytes),
+            "exclusive_avg_launch_us": round(times[dom][0] * 1e3 / times[dom][1], 2),
+            "exclusive_frac": round(dom_bytes / (times[dom][0] * 1e-3 / times[dom][1]) / 1e9 / HBM_PEAK_GBS, 5)}
     # the matcher is VALU-bound (xor+popcount), not HBM-bound: report its VALU fraction beside it
     if "k_hamming_knn2" in times:
         ms, launches = times["k_hamming_knn2"]
         pairs_eval = sum(nq * nt for nq, nt in pairs_rows)
         rate = pairs_eval / (ms * 1e-3 / launches)
-        valu = {"kernel": "k_hamming_knn2", "descriptor_pairs_per_s": rate, "lane_ops_per_pair": 19,
-                "peak_lane_ops_per_s": VALU_PEAK_LANEOPS, "frac": round(19 * rate / VALU_PEAK_LANEOPS, 4)}
+        valu = {"kernel": "k_hamming_knn2", "descriptor_pairs_per_s": rate, "valu_instructions_per_pair": 19,
+                "issue_cycles_per_pair": round(MATCH_CYCLES_PER_PAIR, 2), "peak_pairs_per_s": VALU_PEAK_PAIRS,
+                "frac": round(rate / VALU_PEAK_PAIRS, 4), "timing": "exclusive pass"}
     else:
         valu = None
 
@@ -208,13 +243,13 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: VGA %dx%d stream, %d features/frame, 8 levels, extract + MatchByBruteForce vs previous frame" % (W, H, args.features),
                        "frames_per_step": B, "parallelism": "frames sharded over %d rank(s), replicas, no collective on the data path" % world,
-                       "host_threads": os.environ.get("SSVIO_HOST_THREADS", "auto")},
+                       "steps_in_flight": S},
             "keypoints_per_frame": round(float(counts.mean()), 1),
             "matches_per_frame": round(float(nmatch.mean()), 1),
             "query_matches_per_s": round(float(nmatch.sum()) * args.steps * world / dt, 1),
             "roofline": roof, "valu": valu, "kernels": kern,
             "kernel_events": {"roofline": "hipEvent pairs around %s in the timed region" % dom,
-                              "kernels": "timed region" if args.all_kernel_events else "second pass of the same steps, pairs around every kernel"},
+                              "kernels": "second pass of the same steps, one step in flight, pairs around every kernel (exclusive times)"},
             "host_waits": "per step" if args.sync_steps else "none inside the timed region (pipelined)",
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -222,7 +257,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    ex.close(); fm.close()
+    for h in exs + fms:
+        h.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
