@@ -375,7 +375,7 @@ static int orb_run(ssvio_orb* h, int batch, bool wait = true)
         a.kl = h->kl; a.raw = h->d_raw; a.rawCount = h->d_rawCount; a.cellIni = h->d_cellIni;
         a.rawPerFrame = g.slotsPerFrame; a.cellsPerFrame = g.cellsPerFrame;
         a.kval = h->d_kval; a.kord = h->d_kord; a.knode = h->d_knode;
-        a.sel = h->d_sel; a.selCount = h->d_selCount; a.selPerFrame = h->kpCap;
+        a.sel = h->d_sel; a.selCount = h->d_selCount; a.selPerFrame = h->kpCap; a.batch = batch;
         ProfScope p(h->prof, "k_quadtree", s);
         if (launch_quadtree(a, h->maxAlive, g.nlevels, batch, s)) { set_error("internal: quadtree capacity"); return SSVIO_ERR_INVALID; }
     }

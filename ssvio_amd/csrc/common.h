@@ -88,6 +88,7 @@ struct QtArgs {
     size_t rawPerFrame; int cellsPerFrame;
     uint32_t* kval; uint32_t* kord; uint32_t* knode;     // per-key scratch, same indexing as raw
     uint2* sel; int* selCount; int selPerFrame;
+    int batch;
 };
 
 struct ExtractorTables {
@@ -133,6 +134,28 @@ struct ProfScope {
     ProfScope(KernelProfiler& p_, const char* name, hipStream_t s_) : p(p_), s(s_), on(p_.enabled && (!p_.only || strcmp(p_.only, name) == 0)) { if (on) p.begin(name, s); }
     ~ProfScope() { if (on) p.end(s); }
 };
+
+#if defined(__HIPCC__)
+// Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  This mapping sends all
+// workgroups of a frame to ONE XCD (frame f -> XCD f % 8), so that a frame's pyramid is fetched into one L2 only and
+// neighbouring tiles / keypoints of the frame find each other's lines there.  Frames beyond the last multiple of 8 keep
+// the plain order.  (Affinity is for speed only: nothing depends on where a workgroup runs.)
+__device__ __forceinline__ void xcd_frame_block(unsigned id, int blocksPerFrame, int batch, int& frame, int& blk)
+{
+    const unsigned full = (unsigned)(batch & ~7) * (unsigned)blocksPerFrame;      // workgroups of the frames in complete groups of 8
+    if (id < full) {
+        const unsigned xcd = id & 7u, slot = id >> 3;
+        const unsigned g = slot / (unsigned)blocksPerFrame;
+        blk = (int)(slot - g * blocksPerFrame);
+        frame = (int)(g * 8u + xcd);
+    } else {
+        const unsigned r = id - full, f = r / (unsigned)blocksPerFrame;
+        blk = (int)(r - f * blocksPerFrame);
+        frame = (batch & ~7) + (int)f;
+    }
+}
+
+#endif
 
 // ---------------------------------------------------------------- kernel launchers (defined in *.hip)
 // candidates are packed as x | y<<12 | score<<24 (x,y relative to minBorder)

@@ -29,20 +29,24 @@ __device__ __forceinline__ int refl_clamp(int p, int n) { return min(max(refl101
 template <int CH>
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int w, int h, int stride, size_t frameStride,
                                                 uint8_t* __restrict__ pyr, size_t pyrFrameBytes, int pitch0, int aligned4,
-                                                int* __restrict__ zeroA, int nA, int* __restrict__ zeroB, int nB)
+                                                int* __restrict__ zeroA, int nA, int* __restrict__ zeroB, int nB,
+                                                int gx, int blocksPerFrame, int batch)
 {
+    int frame, blk;
+    xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
+    const int by = blk / gx, bx = blk - by * gx;
     // first kernel of the pipeline: it also clears the FAST stage's counters (no separate memset launches)
     {
-        const unsigned nthreads = gridDim.x * gridDim.y * gridDim.z * 256u;
-        const unsigned flat = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+        const unsigned nthreads = gridDim.x * 256u;
+        const unsigned flat = blockIdx.x * 256u + threadIdx.x;
         for (unsigned i = flat; i < (unsigned)nA; i += nthreads) zeroA[i] = 0;
         for (unsigned i = flat; i < (unsigned)nB; i += nthreads) zeroB[i] = 0;
     }
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - kPadX;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = (bx * 64 + (threadIdx.x & 63)) * 4 - kPadX;
+    const int y = by * 4 + (threadIdx.x >> 6);
     if (x0 >= w + kPadX || y >= h) return;
-    const uint8_t* s = src + (size_t)blockIdx.z * frameStride + (size_t)y * stride;
-    uint8_t* d = pyr + (size_t)blockIdx.z * pyrFrameBytes + (size_t)y * pitch0 + x0;
+    const uint8_t* s = src + (size_t)frame * frameStride + (size_t)y * stride;
+    uint8_t* d = pyr + (size_t)frame * pyrFrameBytes + (size_t)y * pitch0 + x0;
     uint32_t v = 0;
     if (CH == 1 && aligned4 && x0 >= 0 && x0 + 3 < w) v = *(const uint32_t*)(s + x0);
     else {
@@ -61,15 +65,17 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src,
 void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
                       uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s)
 {
-    dim3 grid((w + 2 * kPadX + 255) / 256, (h + 3) / 4, batch);
+    const int gx = (w + 2 * kPadX + 255) / 256, bpf = gx * ((h + 3) / 4);
     const int aligned4 = ((uintptr_t)src % 4 == 0) && (stride % 4 == 0) && (frameStride % 4 == 0);
-    hipLaunchKernelGGL(k_level0<1>, grid, dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, aligned4, zeroA, nA, zeroB, nB);
+    hipLaunchKernelGGL(k_level0<1>, dim3(bpf * batch), dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, aligned4, zeroA, nA, zeroB, nB,
+                       gx, bpf, batch);
 }
 void launch_rgb2gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
                      uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s)
 {
-    dim3 grid((w + 2 * kPadX + 255) / 256, (h + 3) / 4, batch);
-    hipLaunchKernelGGL(k_level0<3>, grid, dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, 0, zeroA, nA, zeroB, nB);
+    const int gx = (w + 2 * kPadX + 255) / 256, bpf = gx * ((h + 3) / 4);
+    hipLaunchKernelGGL(k_level0<3>, dim3(bpf * batch), dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, 0, zeroA, nA, zeroB, nB,
+                       gx, bpf, batch);
 }
 
 // ---------------------------------------------------------------------------
@@ -79,13 +85,17 @@ void launch_rgb2gray(const uint8_t* src, int w, int h, int stride, size_t frameS
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_t pyrFrameBytes,
                                                 unsigned long long srcOff, int srcPitch,
                                                 unsigned long long dstOff, int dstPitch, int dw, int dh,
-                                                const short4* __restrict__ xtab, const short4* __restrict__ ytab, int area2)
+                                                const short4* __restrict__ xtab, const short4* __restrict__ ytab, int area2,
+                                                int gx, int blocksPerFrame, int batch)
 {
-    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - kPadX;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int frame, blk;
+    xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
+    const int by = blk / gx, bx = blk - by * gx;
+    const int x0 = (bx * 64 + (threadIdx.x & 63)) * 4 - kPadX;
+    const int y = by * 4 + (threadIdx.x >> 6);
     if (x0 >= dw + kPadX || y >= dh) return;
-    const uint8_t* S = pyr + (size_t)blockIdx.z * pyrFrameBytes + srcOff;
-    uint8_t* D = pyr + (size_t)blockIdx.z * pyrFrameBytes + dstOff + (size_t)y * dstPitch + x0;
+    const uint8_t* S = pyr + (size_t)frame * pyrFrameBytes + srcOff;
+    uint8_t* D = pyr + (size_t)frame * pyrFrameBytes + dstOff + (size_t)y * dstPitch + x0;
     uint32_t v = 0;
     if (area2) {       // exact 2:1 shrink: cv::resize uses INTER_AREA, (a+b+c+d+2)>>2
         const uint8_t* A = S + (size_t)(2 * y) * srcPitch; const uint8_t* B = A + srcPitch;
@@ -124,18 +134,22 @@ constexpr int kResizeSrcRows = 12;
 __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, size_t pyrFrameBytes,
                                                      unsigned long long srcOff, int srcPitch,
                                                      unsigned long long dstOff, int dstPitch, int nq, int dh, int rows,
-                                                     const ResizeQuad* __restrict__ qtab, const short4* __restrict__ ytab)
+                                                     const ResizeQuad* __restrict__ qtab, const short4* __restrict__ ytab,
+                                                     int gx, int blocksPerFrame, int batch)
 {
-    const int qi = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int strip = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    int frame, blk;
+    xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
+    const int by = blk / gx, bx = blk - by * gx;
+    const int qi = bx * 64 + (threadIdx.x & 63);
+    const int strip = __builtin_amdgcn_readfirstlane(by * 4 + (threadIdx.x >> 6));
     const int yBeg = strip * rows;
     if (yBeg >= dh) return;
     const int yEnd = min(yBeg + rows, dh);
     const bool live = qi < nq;
     const ResizeQuad e = qtab[live ? qi : 0];
     const uint32_t b = e.bOff & 0xFFFFFF, off = e.bOff >> 24;
-    const uint8_t* S = pyr + (size_t)blockIdx.z * pyrFrameBytes + srcOff;
-    uint8_t* D = pyr + (size_t)blockIdx.z * pyrFrameBytes + dstOff + 4 * qi - kPadX;
+    const uint8_t* S = pyr + (size_t)frame * pyrFrameBytes + srcOff;
+    uint8_t* D = pyr + (size_t)frame * pyrFrameBytes + dstOff + 4 * qi - kPadX;
     const int sBeg = ytab[yBeg].x, sEnd = ytab[yEnd - 1].y;                   // wave-uniform
     uint32_t A[kResizeSrcRows], B[kResizeSrcRows], C[kResizeSrcRows];
 #pragma unroll
@@ -176,16 +190,16 @@ void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int le
     const int dw = kl.lv[level].w, dh = kl.lv[level].h;
     if (mode == 1) {
         const int nq = (dw + 2 * kPadX + 3) / 4;
-        dim3 grid((nq + 63) / 64, (dh + 4 * rows - 1) / (4 * rows), batch);
-        hipLaunchKernelGGL(k_resize_quad, grid, dim3(256), 0, s, pyr, pyrFrameBytes,
+        const int gx = (nq + 63) / 64, bpf = gx * ((dh + 4 * rows - 1) / (4 * rows));
+        hipLaunchKernelGGL(k_resize_quad, dim3(bpf * batch), dim3(256), 0, s, pyr, pyrFrameBytes,
                            kl.lv[level - 1].offset, kl.lv[level - 1].pitch, kl.lv[level].offset, kl.lv[level].pitch, nq, dh, rows,
-                           (const ResizeQuad*)(tabs + quadTabOff), (const short4*)(tabs + yTabOff));
+                           (const ResizeQuad*)(tabs + quadTabOff), (const short4*)(tabs + yTabOff), gx, bpf, batch);
         return;
     }
-    dim3 grid((dw + 2 * kPadX + 255) / 256, (dh + 3) / 4, batch);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, pyr, pyrFrameBytes,
+    const int gx = (dw + 2 * kPadX + 255) / 256, bpf = gx * ((dh + 3) / 4);
+    hipLaunchKernelGGL(k_resize, dim3(bpf * batch), dim3(256), 0, s, pyr, pyrFrameBytes,
                        kl.lv[level - 1].offset, kl.lv[level - 1].pitch, kl.lv[level].offset, kl.lv[level].pitch, dw, dh,
-                       (const short4*)(tabs + xTabOff), (const short4*)(tabs + yTabOff), mode == 2 ? 1 : 0);
+                       (const short4*)(tabs + xTabOff), (const short4*)(tabs + yTabOff), mode == 2 ? 1 : 0, gx, bpf, batch);
 }
 
 // ---------------------------------------------------------------------------
@@ -238,7 +252,7 @@ __device__ __forceinline__ int find_fast_level(const KLevels& kl, int id)
 template <int FH>
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, size_t pyrFrameBytes, KLevels kl, int cellsPerFrame,
                                               size_t rawPerFrame, int iniTh, int minTh, uint2* __restrict__ raw,
-                                              int* __restrict__ rawCount, int* __restrict__ cellIni)
+                                              int* __restrict__ rawCount, int* __restrict__ cellIni, int tilesPerFrame, int batch)
 {
     constexpr int kFtH = FH, kFtRows = FH + 8, kScRows = FH + 2;
     constexpr int kLoadPasses = (kFtRows + 13) / 14, kScanPasses = (kScRows + 13) / 14;      // rows r0, r0+14, ... per thread
@@ -247,10 +261,12 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     __shared__ uint16_t queue[kScRows * kFtPitch];
     __shared__ uint2 outbuf[kFtW * kFtH / 4];            // NMS survivors of one tile: no two are 8-adjacent within a cell
     __shared__ int qn, on, obase;
-    const int tid = threadIdx.x, frame = blockIdx.y;
-    const int level = find_fast_level<FH == 64>(kl, blockIdx.x);
+    const int tid = threadIdx.x;
+    int frame, tileId;
+    xcd_frame_block(blockIdx.x, tilesPerFrame, batch, frame, tileId);
+    const int level = find_fast_level<FH == 64>(kl, tileId);
     const KLevel& L = kl.lv[level];
-    const int t = blockIdx.x - (FH == 64 ? L.fastTileBaseT : L.fastTileBase);
+    const int t = tileId - (FH == 64 ? L.fastTileBaseT : L.fastTileBase);
     const int tyi = t / L.fastTilesX, txi = t - tyi * L.fastTilesX;
     const int w = L.w, h = L.h, pitch = L.pitch;
     const int x0 = txi * kFtW, y0 = tyi * kFtH;
@@ -407,10 +423,10 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
 void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame, bool tall, int cellsPerFrame, size_t rawPerFrame,
                  int iniTh, int minTh, uint2* raw, int* rawCount, int* cellIni, int batch, hipStream_t s)
 {
-    if (tall) hipLaunchKernelGGL(k_fast<64>, dim3(tilesPerFrame, batch), dim3(256), 0, s, pyr, pyrFrameBytes, kl, cellsPerFrame, rawPerFrame,
-                                 iniTh, minTh, raw, rawCount, cellIni);
-    else hipLaunchKernelGGL(k_fast<32>, dim3(tilesPerFrame, batch), dim3(256), 0, s, pyr, pyrFrameBytes, kl, cellsPerFrame, rawPerFrame,
-                            iniTh, minTh, raw, rawCount, cellIni);
+    if (tall) hipLaunchKernelGGL(k_fast<64>, dim3(tilesPerFrame * batch), dim3(256), 0, s, pyr, pyrFrameBytes, kl, cellsPerFrame, rawPerFrame,
+                                 iniTh, minTh, raw, rawCount, cellIni, tilesPerFrame, batch);
+    else hipLaunchKernelGGL(k_fast<32>, dim3(tilesPerFrame * batch), dim3(256), 0, s, pyr, pyrFrameBytes, kl, cellsPerFrame, rawPerFrame,
+                            iniTh, minTh, raw, rawCount, cellIni, tilesPerFrame, batch);
 }
 
 // ---------------------------------------------------------------------------
@@ -462,11 +478,13 @@ __device__ __forceinline__ uint32_t blur_col4(const uint32_t (&a)[4], const uint
     return out;
 }
 
-__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, size_t pyrFrameBytes, KLevels kl)
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, size_t pyrFrameBytes, KLevels kl,
+                                              int blocksPerFrame, int batch)
 {
     const int lane = threadIdx.x & 31;
-    const int strip = blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int frame = blockIdx.y;
+    int frame, blk;
+    xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
+    const int strip = blk * 8 + (threadIdx.x >> 5);
     const bool live = strip < kl.lv[kl.nlevels].blurStripBase;
     int level = 0;
 #pragma unroll
@@ -520,7 +538,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 
 void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int stripsPerFrame, int batch, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_blur, dim3((stripsPerFrame + 7) / 8, batch), dim3(256), 0, s, pyr, blur, pyrFrameBytes, kl);
+    const int bpf = (stripsPerFrame + 7) / 8;
+    hipLaunchKernelGGL(k_blur, dim3(bpf * batch), dim3(256), 0, s, pyr, blur, pyrFrameBytes, kl, bpf, batch);
 }
 
 // ---------------------------------------------------------------------------
@@ -636,10 +655,12 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
                                                   size_t pyrFrameBytes, KLevels kl, const uint2* __restrict__ sel,
                                                   const int* __restrict__ selCount, int selPerFrame, int cap,
                                                   ssvio_keypoint* __restrict__ kpOut, uint8_t* __restrict__ desc, int* __restrict__ kpCount,
-                                                  int* __restrict__ kpCountHost)
+                                                  int* __restrict__ kpCountHost, int blocksPerFrame, int batch)
 {
-    const int frame = blockIdx.y, lane = threadIdx.x & 63, sl = lane & 31, half = lane >> 5;
-    const int k = (blockIdx.x * (kDescThreads / 64) + (threadIdx.x >> 6)) * 2 + half;
+    int frame, blk;
+    xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
+    const int lane = threadIdx.x & 63, sl = lane & 31, half = lane >> 5;
+    const int k = (blk * (kDescThreads / 64) + (threadIdx.x >> 6)) * 2 + half;
     // the 4-KB test pattern is fetched once per workgroup; every wave then reads its records from LDS
     __shared__ float4 spat[256];
     if (threadIdx.x < 256) spat[threadIdx.x] = ((const float4*)c_patf.v)[threadIdx.x];
@@ -658,7 +679,7 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
         before = __shfl(incl, max(level - 1, 0), 16);                 // lanes 0..15 of the same half
         if (level == 0) before = 0;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { kpCount[frame] = total; kpCountHost[frame] = total; }   // second copy lands in pinned host memory
+    if (blk == 0 && threadIdx.x == 0) { kpCount[frame] = total; kpCountHost[frame] = total; }   // second copy lands in pinned host memory
     if (__builtin_amdgcn_readfirstlane(k) >= total) return;        // the lower half's keypoint is the smaller index
     const bool live = k < total;
     if (!live) level = 0;
@@ -755,8 +776,9 @@ void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameByt
                      const uint2* sel, const int* selCount, int selPerFrame, int cap, ssvio_keypoint* kpOut, uint8_t* desc,
                      int* kpCount, int* kpCountHost, int batch, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_describe, dim3((cap + kDescThreads / 32 - 1) / (kDescThreads / 32), batch), dim3(kDescThreads), 0, s, pyr, blur, pyrFrameBytes, kl, sel, selCount, selPerFrame,
-                       cap, kpOut, desc, kpCount, kpCountHost);
+    const int bpf = (cap + kDescThreads / 32 - 1) / (kDescThreads / 32);
+    hipLaunchKernelGGL(k_describe, dim3(bpf * batch), dim3(kDescThreads), 0, s, pyr, blur, pyrFrameBytes, kl, sel, selCount, selPerFrame,
+                       cap, kpOut, desc, kpCount, kpCountHost, bpf, batch);
 }
 
 }  // namespace ssvio

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
     QtShared* sh = (QtShared*)p;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int level = blockIdx.x, frame = blockIdx.y;
+    int frame, level;
+    xcd_frame_block(blockIdx.x, a.kl.nlevels, a.batch, frame, level);      // frame f -> XCD f % 8, like the kernels around it
     const KLevel& L = a.kl.lv[level];
     const int N = L.quota;
     const int H = L.h - 2 * kMinBorder;                       // maxY - minY
@@ -331,8 +332,8 @@ int launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipSt
         (void)hipFuncSetAttribute((const void*)k_quadtree<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(2048));
         attrSet = true;
     }
-    if (maxAlive <= 1024) hipLaunchKernelGGL(k_quadtree<1024>, dim3(nlevels, batch), dim3(kQtThreads), quadtree_lds_bytes(1024), s, a);
-    else if (maxAlive <= 2048) hipLaunchKernelGGL(k_quadtree<2048>, dim3(nlevels, batch), dim3(kQtThreads), quadtree_lds_bytes(2048), s, a);
+    if (maxAlive <= 1024) hipLaunchKernelGGL(k_quadtree<1024>, dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(1024), s, a);
+    else if (maxAlive <= 2048) hipLaunchKernelGGL(k_quadtree<2048>, dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(2048), s, a);
     else return -1;
     return 0;
 }
