@@ -74,11 +74,119 @@ def cpu_baseline(frames, nfeatures, budget_s=12.0):
             O.match_bruteforce(d, prev)
         prev = d
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 4 * len(frames):
+        if time.perf_counter() - t0 > budget_s or n >= 8 * len(frames):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d VGA frames (extract %d features + BF match vs previous), oracle C restatement, 1 thread, %.1f s" % (n, nfeatures, dt)}
+
+
+class _DevBytes:
+    """a device buffer owned by the library, presented to torch through __cuda_array_interface__ (no copy)"""
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def batched_matching(rank, world, dev, dist, iters=10):
+    """BASELINE configs 4 and 5: keyframe-pair blocks are dealt round-robin to the ranks, every rank
+    matches its share on its GPU, and ONE all_gather (RCCL over xGMI when world > 1) returns the best-match lists
+    (config 4) or 16-byte per-pair summaries (config 5).  Outside the frames/s timed region; reported beside it."""
+    import ssvio_amd
+    from ssvio_amd import synth, dist as D, _lib as L
+    fm = ssvio_amd.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6}, device=dev.index)
+    st = torch.cuda.Stream(device=dev)                            # matcher kernels, the staging copies and the collective
+    fm.set_stream(st.cuda_stream)                                 # are all ordered on this one (non-null) stream
+    out = []
+    on_cpu = bool(dist) and dist.get_backend() != "nccl"          # gloo rehearsal: the gather goes through host tensors
+
+    def gather(dst, src):
+        if not dist:
+            dst[0].copy_(src)
+        elif on_cpu:
+            st.synchronize()
+            parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
+            dist.all_gather(parts, src.cpu())
+            dst.copy_(torch.stack(parts).to(dev))
+        else:
+            dist.all_gather(list(dst.unbind(0)), src)
+
+    def timed(fn):
+        with torch.cuda.stream(st):
+            for _ in range(2):
+                fn()
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(st):
+            for _ in range(iters):
+                fn()
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / iters
+
+    # ---- config 4: 1 query frame x 64 keyframes x 4000 descriptors, cross-check; the 64 pair-blocks are split over the ranks
+    rows, nkf = 4000, 64
+    q, base = synth.descriptor_sets(400, rows * nkf, rows)
+    d = torch.from_numpy(np.concatenate([base, q])).to(dev)             # set 0 = query frame, sets 1..64 = keyframes
+    cnt = torch.full((nkf + 1,), rows, dtype=torch.int32, device=dev)
+    pairs = np.array([[0, k + 1] for k in range(nkf)], np.int32)
+    mine = D.shard_pairs(nkf, rank, world)
+    per = (nkf + world - 1) // world
+    gathered = torch.empty((world, per * rows * 16 + per * 4), dtype=torch.uint8, device=dev)
+    local = torch.zeros(per * rows * 16 + per * 4, dtype=torch.uint8, device=dev)
+
+    def cfg4():
+        if len(mine):
+            dm, dn = fm.match_batch_dev(d, rows, rows, cnt, pairs[mine], L.MODE_CROSSCHECK)
+            n = len(mine)
+            local[:n * rows * 16].copy_(torch.as_tensor(_DevBytes(dm, n * rows * 16), device=dev))
+            local[per * rows * 16:per * rows * 16 + n * 4].copy_(torch.as_tensor(_DevBytes(dn, n * 4), device=dev))
+        gather(gathered, local)
+
+    trace('cfg4 start')
+    dt = timed(cfg4)
+    trace('cfg4 done')
+    nm = gathered[:, per * rows * 16:].contiguous().view(torch.int32).cpu().numpy().reshape(world, per)
+    total = int(sum(nm[r % world, r // world] for r in range(nkf)))
+    out.append({"config": "configs[3]: 1 query x %d keyframes x %d descriptors, cross-check, pair-blocks over %d rank(s), all_gather of DMatch lists (%d KB per rank)"
+                % (nkf, rows, world, (per * rows * 16 + per * 4) // 1024),
+                "scaling": "strong", "ms": round(dt * 1e3, 4), "descriptor_pairs_per_s": 2.0 * nkf * rows * rows / dt,
+                "query_matches_per_s": total / dt, "matches": total})
+
+    # ---- config 5 (subset): loop-candidate all-pairs, 8000 descriptors per keyframe; every rank takes 128 pair-blocks
+    # of the 276 unordered pairs of 24 keyframes (weak scaling), all_gather of 16-byte per-pair summaries
+    rows5, nset5, P = 8000, 24, 128
+    q5, _ = synth.descriptor_sets(500, rows5 * nset5, rows5)
+    d5 = torch.from_numpy(q5).to(dev)
+    cnt5 = torch.full((nset5,), rows5, dtype=torch.int32, device=dev)
+    allp = D.all_pairs(nset5)
+    mine5 = (rank * 37 + np.arange(P)) % len(allp)
+    g5 = torch.empty((world, P), dtype=torch.int32, device=dev)
+
+    def cfg5():
+        dm, dn = fm.match_batch_dev(d5, rows5, rows5, cnt5, allp[mine5], L.MODE_BRUTEFORCE)
+        loc = torch.as_tensor(_DevBytes(dn, P * 4), device=dev).view(torch.int32)
+        gather(g5, loc)
+
+    dt5 = timed(cfg5)
+    trace('cfg5 done')
+    total5 = int(g5.sum().item())
+    out.append({"config": "configs[4] subset: %d pair-blocks of %dx%d per rank (of the 276 pairs of 24 keyframes), MatchByBruteForce, all_gather of per-pair match counts"
+                % (P, rows5, rows5), "scaling": "weak", "ms": round(dt5 * 1e3, 4),
+                "descriptor_pairs_per_s": float(world) * P * rows5 * rows5 / dt5, "query_matches_per_s": total5 / dt5, "matches": total5,
+                "valu_frac": round(float(world) * P * rows5 * rows5 / dt5 / (world * VALU_PEAK_PAIRS), 4)})
+    fm.close()
+    return out
+
+
+def trace(msg):
+    if os.environ.get("SSVIO_BENCH_TRACE"):
+        print("[bench rank %s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -91,6 +199,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--features", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched-matching", action="store_true", help="skip the configs[3]/[4] matching section")
     ap.add_argument("--sync-steps", action="store_true", help="host waits for every step (latency mode)")
     ap.add_argument("--streams", type=int, default=2, help="steps in flight: step i runs on handle pair i %% streams, each pair on its own HIP stream")
     ap.add_argument("--all-kernel-events", action="store_true", help="hipEvent pairs around every kernel in the timed region (slower)")
@@ -102,13 +211,21 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rehearsal knobs for a one-GPU box: SSVIO_BENCH_BACKEND=gloo SSVIO_BENCH_ONE_DEVICE=1 put every rank on cuda:0
+        if os.environ.get("SSVIO_BENCH_ONE_DEVICE"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SSVIO_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
+    trace('process group up')
     import ssvio_amd
     from ssvio_amd import synth, _lib as L
 
@@ -155,6 +272,7 @@ def main():
                 tot[k] = (a + ms, c + n)
         return tot
 
+    trace('handles created')
     for _ in range(max(args.warmup, S)):        # every pair allocates on its first step
         step()
     sync_all()
@@ -176,6 +294,7 @@ def main():
     else:
         profiling(True, only_ex=dom if dom_is_ex else None, only_fm=None if dom_is_ex else dom)
     torch.cuda.synchronize()
+    trace('before timed region')
     if dist: dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -194,6 +313,7 @@ def main():
     else:
         total_frames = B * args.steps
 
+    trace('timed region done, dt %.4f' % dt)
     # per-kernel GPU time over the timed region
     times = kernel_times()
     dom_ms, dom_launches = times[dom]
@@ -234,6 +354,8 @@ def main():
     else:
         valu = None
 
+    trace('kernel table done')
+    bm = None if args.no_batched_matching else batched_matching(rank, world, dev, dist)
     if rank == 0:
         out = {
             "metric": "ORB extract + BF-match frames/s @VGA (BASELINE config 2)",
@@ -251,6 +373,7 @@ def main():
             "kernel_events": {"roofline": "hipEvent pairs around %s in the timed region" % dom,
                               "kernels": "second pass of the same steps, one step in flight, pairs around every kernel (exclusive times)"},
             "host_waits": "per step" if args.sync_steps else "none inside the timed region (pipelined)",
+            "batched_matching": bm,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, args.features)

@@ -15,7 +15,7 @@ print("value", d["value"], "ms/step", d["ms_per_step"], "roof", d["roofline"]["k
 for k,v in d["kernels"].items(): print("  %-18s avg_us %8.2f  launches %4d  GB/s %s"%(k,v["avg_us"],v["launches"],v["GBps"]))
 PY
 for extra in "--all-kernel-events" "--sync-steps" "--sync-steps --batch 1 --steps 200"; do
-  timeout -k 10 200 python -u bench.py --steps 20 --warmup 3 --no-cpu-baseline $extra 2>/dev/null | python -c "
+  timeout -k 10 200 python -u bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-batched-matching $extra 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$extra', 'value', d['value'], 'ms/step', d['ms_per_step'])" || exit 1
 done
