@@ -33,6 +33,23 @@ MATCH_CYCLES_PER_PAIR = 8 * 2.46 + 11 * 4.13
 VALU_PEAK_PAIRS = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR      # 1024 SIMDs x 2.4 GHz x 64 lanes = 2.42e12 pairs/s
 
 
+PMC_FILE = os.path.join(ROOT, "profiles", "r1", "r1_final_pmc_hbm.json")
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over this same command
+    (tools/gpu_profile.sh: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950 as
+    MI355X_MICROARCH.md prescribes).  bench.py cannot run the profiler on itself; None when the file is absent."""
+    try:
+        d = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None
+    for name, c in d.items():
+        if name.split("::")[-1].split("<")[0] in (kernel, kernel + "_quad") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return int(c["FETCH_SIZE"]["avg_bytes_corrected"] + c["WRITE_SIZE"]["avg_bytes_corrected"])
+    return None
+
+
 def level_pixels(ex, w, h):
     return [ex.level_geometry(w, h, l)["w"] * ex.level_geometry(w, h, l)["h"] for l in range(ex.nlevels)]
 
@@ -339,7 +356,8 @@ def main():
     dom_bytes = algorithmic_bytes(dom, B, px, int(counts.sum()), pairs_rows)
     achieved = dom_bytes / dom_avg_s / 1e9
     roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom) if (B, W, H, args.features) == (64, 640, 480, 1000) else None,
+            "traffic_source": "profiles/r1/r1_final_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, default batch)",
             "avg_launch_us": round(dom_avg_s * 1e6, 2), "alg_bytes_per_launch": int(dom_bytes),
             "exclusive_avg_launch_us": round(times[dom][0] * 1e3 / times[dom][1], 2),
             "exclusive_frac": round(dom_bytes / (times[dom][0] * 1e-3 / times[dom][1]) / 1e9 / HBM_PEAK_GBS, 5)}
