@@ -223,21 +223,25 @@ constexpr int kFtPitch = 72;                 // LDS row bytes: x0-4 .. x0+67
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 
-// max over the 16 circular arcs of 9 of min(d): both polarities at once in packed i16
-// (.x = v - ring -> dark arcs, .y = ring - v -> bright arcs)
-__device__ __forceinline__ short2v arc9_maxmin_pk(const short2v (&p)[16])
+// cv::FAST corner score from the 16 ring differences d[k] = v - ring[k]:
+//   dark arcs:   max over the 16 circular arcs of 9 of min(d)
+//   bright arcs: max over arcs of min(-d) = -(min over arcs of max(d))
+// score = max(dark, bright) - 1.  Windows of 9 = three windows of 3 (v_min3 / v_max3): 96 instructions.
+__device__ __forceinline__ int arc9_score(const int (&d)[16])
 {
-    short2v m2[16], m4[16], m8[16];
+    int mn3[16], mx3[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m2[k] = __builtin_elementwise_min(p[k], p[(k + 1) & 15]);
+    for (int k = 0; k < 16; ++k) {
+        mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    }
+    int a = -512, b = 512;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
-    short2v r = __builtin_elementwise_min(m8[0], p[8]);
-#pragma unroll
-    for (int k = 1; k < 16; ++k) r = __builtin_elementwise_max(r, __builtin_elementwise_min(m8[k], p[(k + 8) & 15]));
-    return r;
+    for (int k = 0; k < 16; ++k) {
+        a = max(a, min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
+        b = min(b, max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]));
+    }
+    return max(a, -b) - 1;
 }
 
 template <bool TALL>
@@ -298,47 +302,46 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     // phase 1, packed: a 9-arc always contains two ADJACENT compass pixels (ring 0,4,8,12); "some adjacent
     // compass pair in one class" == (down|up) & (left|right) per class.  Two pixels per packed-i16 register.
     // Domain: score rows y0-1 .. y0+32 (r = 0..33), quad columns x0-4 .. x0+67 (pixels outside x0-1 .. x0+64 dropped).
-    unsigned flags = 0;                                     // bit (4k+i): pixel i of this thread's quad k survives (kScanPasses <= 5)
+    unsigned flags = 0;                                     // bit (8i+k): pixel i of this thread's quad of pass k survives (kScanPasses <= 5)
     const short2v T2 = short2v{(short)tLow, (short)tLow};
     // tile (with its 1-px halo) entirely inside the tested region [19, w-20] x [19, h-20]?
     const bool allValid = x0 - 1 >= kEdge && x0 + kFtW <= w - kEdge - 1 && y0 - 1 >= kEdge && y0 + kFtH <= h - kEdge - 1;
     const int qc = c0;
+    // pixels of the score domain x0-1 .. x0+64 only (quad columns 0 and 17 are partial); one sign byte per pixel
+    const uint32_t colMask = !lane252 ? 0u : (qc == 0 ? 0x80000000u : (qc == 17 ? 0x00000080u : 0x80808080u));
 #pragma unroll
     for (int k = 0; k < kScanPasses; ++k) {
         const int r = min(r0 + 14 * k, kScRows - 1);
-        const bool qlive = lane252 && r0 + 14 * k < kScRows;
+        const bool qlive = r0 + 14 * k < kScRows;
         const int rowC = (r + 3) * (kFtPitch / 4);          // input row of score row r
         const uint32_t C = tile[rowC + qc], Lf = tile[rowC + max(qc - 1, 0)], Rt = tile[rowC + min(qc + 1, 17)];
         const uint32_t U = tile[rowC - 3 * (kFtPitch / 4) + qc], D = tile[rowC + 3 * (kFtPitch / 4) + qc];
         const uint32_t lw = __builtin_amdgcn_alignbyte(C, Lf, 1);     // bytes x-3 .. x
         const uint32_t rw = __builtin_amdgcn_alignbyte(Rt, C, 3);     // bytes x+3 .. x+6
-        unsigned f4 = 0;
+        uint32_t sgn[2];
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
             const uint32_t sel = hlf ? 0x0c030c02u : 0x0c010c00u;      // bytes (0,1) or (2,3) -> two u16
             auto pk = [&](uint32_t x) { return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, x, sel)); };
-            const short2v v = pk(C);
-            const short2v du = v - pk(U), dd = v - pk(D), dl = v - pk(lw), dr = v - pk(rw);
-            // some vertical AND some horizontal compass pixel darker than v-T:  min(max(du,dd), max(dl,dr)) > T
-            const short2v dark = __builtin_elementwise_min(__builtin_elementwise_max(du, dd), __builtin_elementwise_max(dl, dr));
-            // ... brighter than v+T:  max(min(du,dd), min(dl,dr)) < -T
-            const short2v brt = __builtin_elementwise_max(__builtin_elementwise_min(du, dd), __builtin_elementwise_min(dl, dr));
-            const uint32_t m = __builtin_bit_cast(uint32_t, (short2v)(((T2 - dark) | (brt + T2)) >> 15));    // sign bits
-            f4 |= ((m & 1u) | ((m >> 15) & 2u)) << (2 * hlf);
+            const short2v v = pk(C), pu = pk(U), pd = pk(D), pl = pk(lw), pr = pk(rw);
+            // darker than v-T on one vertical AND one horizontal compass pixel:  v - max(min(U,D), min(L,R)) > T
+            const short2v A = __builtin_elementwise_max(__builtin_elementwise_min(pu, pd), __builtin_elementwise_min(pl, pr));
+            // brighter than v+T:  min(max(U,D), max(L,R)) - v > T
+            const short2v B = __builtin_elementwise_min(__builtin_elementwise_max(pu, pd), __builtin_elementwise_max(pl, pr));
+            sgn[hlf] = __builtin_bit_cast(uint32_t, (short2v)(T2 - __builtin_elementwise_max(v - A, B - v)));      // negative <=> passes
         }
-        // keep only pixels of the score domain x0-1 .. x0+64 (quad columns 0 and 17 are partial)
-        f4 &= qc == 0 ? 8u : (qc == 17 ? 1u : 15u);
-        f4 = qlive ? f4 : 0u;
+        // the four sign bytes (pixels 0..3) in one dword
+        uint32_t f4 = __builtin_amdgcn_perm(sgn[1], sgn[0], 0x07050301u) & (qlive ? colMask : 0u);
         if (!allValid && f4) {
             const int y = y0 - 1 + r;
             const bool rowOk = y >= kEdge && y <= h - kEdge - 1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int xa = x0 + 4 * qc + i - 4;
-                if (!(rowOk && xa >= kEdge && xa <= w - kEdge - 1)) f4 &= ~(1u << i);
+                if (!(rowOk && xa >= kEdge && xa <= w - kEdge - 1)) f4 &= ~(0x80u << (8 * i));
             }
         }
-        flags |= f4 << (4 * k);
+        flags |= f4 >> (7 - k);
     }
     {   // one queue reservation per wave
         const int lane = tid & 63;
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
             unsigned f = flags;
             while (f) {
                 const int bit = __ffs(f) - 1; f &= f - 1;
-                queue[base++] = (uint16_t)(e0 + (bit >> 2) * (14 * kFtPitch) + (bit & 3));
+                queue[base++] = (uint16_t)(e0 + (bit & 7) * (14 * kFtPitch) + (bit >> 3));
             }
         }
     }
@@ -366,15 +369,14 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
         const int p = queue[q];
         const uint8_t* c = tb + p + 3 * kFtPitch;               // score row r <-> input row r + 3, same columns
         const int v = c[0];
-        short2v d[16];
-#define RING(K, OFF) { const int dd = v - c[OFF]; d[K] = short2v{(short)dd, (short)-dd}; }
+        int d[16];
+#define RING(K, OFF) d[K] = v - c[OFF];
         RING(0, 3 * kFtPitch)      RING(1, 3 * kFtPitch + 1)   RING(2, 2 * kFtPitch + 2)   RING(3, kFtPitch + 3)
         RING(4, 3)                 RING(5, -kFtPitch + 3)      RING(6, -2 * kFtPitch + 2)  RING(7, -3 * kFtPitch + 1)
         RING(8, -3 * kFtPitch)     RING(9, -3 * kFtPitch - 1)  RING(10, -2 * kFtPitch - 2) RING(11, -kFtPitch - 3)
         RING(12, -3)               RING(13, kFtPitch - 3)      RING(14, 2 * kFtPitch - 2)  RING(15, 3 * kFtPitch - 1)
 #undef RING
-        const short2v ab = arc9_maxmin_pk(d);
-        const int s = max((int)ab.x, (int)ab.y) - 1;
+        const int s = arc9_score(d);
         if (s >= tLow && s > 0) ((uint8_t*)sc)[p] = (uint8_t)s;
     }
     __syncthreads();

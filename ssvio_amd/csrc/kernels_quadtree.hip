@@ -20,6 +20,7 @@
 namespace ssvio {
 
 constexpr int kQtThreads = 1024;
+constexpr int kQtRegKeys = 8;            // keys per thread kept in registers (8192 per level); the rest stay in HBM scratch
 
 struct QtShared {
     int wsum[16];
@@ -102,6 +103,12 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
     __syncthreads();
     const int n = sh->n;
     if (n == 0) { if (tid == 0) *selCount = 0; return; }
+    // key k = tid + 1024 j: value and node id live in registers for j < kQtRegKeys, so that the rounds below touch
+    // LDS only (with every key in HBM scratch a round is two chains of dependent global loads: ~10 us)
+    uint32_t rv[kQtRegKeys]; int rn[kQtRegKeys];
+#pragma unroll
+    for (int j = 0; j < kQtRegKeys; ++j) { const int k = tid + j * kQtThreads; rv[j] = k < n ? kval[k] : 0u; rn[j] = 0; }
+    const int nReg = min(n, kQtRegKeys * kQtThreads);            // keys [nReg, n) use kval / knode in HBM
 
     // ---- 1. roots (:574-619)
     const int nIni = L.nIni;
@@ -110,9 +117,18 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
     if (tid < MAXA) { cnt[0][tid] = 0; }
     if (IT > 1) for (int j = 1; j < IT; ++j) cnt[0][tid + j * kQtThreads] = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += kQtThreads) {
+#pragma unroll
+    for (int j = 0; j < kQtRegKeys; ++j) {
+        if (tid + j * kQtThreads < n) {
+            int b = (int)((float)(rv[j] & 0xFFF) / hX);          // vpInitNodes[kp.pt.x / hX], :599
+            b = min(max(b, 0), nIni - 1);
+            rn[j] = b;
+            atomicAdd(&cnt[0][b], 1);
+        }
+    }
+    for (int k = nReg + tid; k < n; k += kQtThreads) {
         const int x = kval[k] & 0xFFF;
-        int b = (int)((float)x / hX);                            // vpInitNodes[kp.pt.x / hX], :599
+        int b = (int)((float)x / hX);
         b = min(max(b, 0), nIni - 1);
         knode[k] = b;
         atomicAdd(&cnt[0][b], 1);
@@ -131,7 +147,9 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
     }
     __syncthreads();
     int Lsize = sh->total;
-    for (int k = tid; k < n; k += kQtThreads) knode[k] = remap[knode[k]];
+#pragma unroll
+    for (int j = 0; j < kQtRegKeys; ++j) rn[j] = remap[rn[j]];
+    for (int k = nReg + tid; k < n; k += kQtThreads) knode[k] = remap[knode[k]];
     __syncthreads();
 
     // ---- 2. rounds
@@ -145,17 +163,18 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
         if (tid == 0) { sh->cut = 1 << 30; sh->nExpand = 0; }
         __syncthreads();
         // (b) key counts per child quadrant (DivideNode :50-69)
-        for (int k = tid; k < n; k += kQtThreads) {
-            const int pn = knode[k];
+        auto count_key = [&](int pn, uint32_t v) {
             if (C[pn] >= 2) {
-                const uint32_t v = kval[k];
                 const int x = v & 0xFFF, y = (v >> 12) & 0xFFF;
                 const uint2 r = R[pn];
                 const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
                 const int hx = x0 + ((x1 - x0 + 1) >> 1), hy = y0 + ((y1 - y0 + 1) >> 1);   // ceil(d / 2), :21-22
                 atomicAdd(&cc[4 * pn + (x < hx ? 0 : 1) + (y < hy ? 0 : 2)], 1);
             }
-        }
+        };
+#pragma unroll
+        for (int j = 0; j < kQtRegKeys; ++j) if (tid + j * kQtThreads < n) count_key(rn[j], rv[j]);
+        for (int k = nReg + tid; k < n; k += kQtThreads) count_key(knode[k], kval[k]);
         __syncthreads();
         // (c) expandable nodes in list order
         int myE[IT], myC[IT], nMine = 0;
@@ -281,17 +300,19 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
         if (myExpand) atomicAdd(&sh->nExpand, myExpand);
         __syncthreads();
         // (g) relabel the keys
-        for (int k = tid; k < n; k += kQtThreads) {
-            const int pn = knode[k];
+        auto relabel = [&](int pn, uint32_t v) -> int {
             if (split[pn]) {
-                const uint32_t v = kval[k];
                 const int x = v & 0xFFF, y = (v >> 12) & 0xFFF;
                 const uint2 r = R[pn];
                 const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
                 const int hx = x0 + ((x1 - x0 + 1) >> 1), hy = y0 + ((y1 - y0 + 1) >> 1);
-                knode[k] = cc[4 * pn + (x < hx ? 0 : 1) + (y < hy ? 0 : 2)];
-            } else knode[k] = remap[pn];
-        }
+                return cc[4 * pn + (x < hx ? 0 : 1) + (y < hy ? 0 : 2)];
+            }
+            return remap[pn];
+        };
+#pragma unroll
+        for (int j = 0; j < kQtRegKeys; ++j) if (tid + j * kQtThreads < n) rn[j] = relabel(rn[j], rv[j]);
+        for (int k = nReg + tid; k < n; k += kQtThreads) knode[k] = relabel(knode[k], kval[k]);
         const int nToExpand = sh->nExpand;
         __syncthreads();
         cur ^= 1;
@@ -305,11 +326,13 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
     unsigned long long* best = skeys;
     for (int i = tid; i < Lsize; i += kQtThreads) best[i] = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += kQtThreads) {
-        const uint32_t v = kval[k];
-        const unsigned long long key = ((unsigned long long)(v >> 24) << 56) | ((unsigned long long)(0x3FFFFFFFu - kord[k]) << 24) | (v & 0xFFFFFFu);
-        atomicMax(&best[knode[k]], key);
-    }
+    auto offer = [&](int node, uint32_t v, uint32_t o) {
+        const unsigned long long key = ((unsigned long long)(v >> 24) << 56) | ((unsigned long long)(0x3FFFFFFFu - o) << 24) | (v & 0xFFFFFFu);
+        atomicMax(&best[node], key);
+    };
+#pragma unroll
+    for (int j = 0; j < kQtRegKeys; ++j) { const int k = tid + j * kQtThreads; if (k < n) offer(rn[j], rv[j], kord[k]); }
+    for (int k = nReg + tid; k < n; k += kQtThreads) offer(knode[k], kval[k], kord[k]);
     __syncthreads();
     for (int i = tid; i < Lsize; i += kQtThreads) {
         const unsigned long long b = best[i];
