@@ -30,11 +30,10 @@ template <int CH>
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src, int w, int h, int stride, size_t frameStride,
                                                 uint8_t* __restrict__ pyr, size_t pyrFrameBytes, int pitch0, int aligned4,
                                                 int* __restrict__ zeroA, int nA, int* __restrict__ zeroB, int nB,
-                                                int gx, int blocksPerFrame, int batch)
+                                                int blocksPerFrame, int batch)
 {
     int frame, blk;
     xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
-    const int by = blk / gx, bx = blk - by * gx;
     // first kernel of the pipeline: it also clears the FAST stage's counters (no separate memset launches)
     {
         const unsigned nthreads = gridDim.x * 256u;
@@ -42,40 +41,45 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src,
         for (unsigned i = flat; i < (unsigned)nA; i += nthreads) zeroA[i] = 0;
         for (unsigned i = flat; i < (unsigned)nB; i += nthreads) zeroB[i] = 0;
     }
-    const int x0 = (bx * 64 + (threadIdx.x & 63)) * 4 - kPadX;
-    const int y = by * 4 + (threadIdx.x >> 6);
-    if (x0 >= w + kPadX || y >= h) return;
+    // a wave takes one row: lane -> quads lane, lane + 64, ...
+    const int y = blk * 4 + (threadIdx.x >> 6);
+    if (y >= h) return;
     const uint8_t* s = src + (size_t)frame * frameStride + (size_t)y * stride;
-    uint8_t* d = pyr + (size_t)frame * pyrFrameBytes + (size_t)y * pitch0 + x0;
-    uint32_t v = 0;
-    if (CH == 1 && aligned4 && x0 >= 0 && x0 + 3 < w) v = *(const uint32_t*)(s + x0);
-    else {
+    uint8_t* d = pyr + (size_t)frame * pyrFrameBytes + (size_t)y * pitch0 - kPadX;
+    const int nq = (w + 2 * kPadX + 3) >> 2;
+#pragma unroll 4
+    for (int q = threadIdx.x & 63; q < nq; q += 64) {
+        const int x0 = 4 * q - kPadX;
+        uint32_t v = 0;
+        if (CH == 1 && aligned4 && x0 >= 0 && x0 + 3 < w) v = *(const uint32_t*)(s + x0);
+        else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = refl_clamp(x0 + i, w);
-            uint32_t g;
-            if (CH == 1) g = s[c];
-            else g = (s[3 * c] * 4899u + s[3 * c + 1] * 9617u + s[3 * c + 2] * 1868u + 8192u) >> 14;
-            v |= g << (8 * i);
+            for (int i = 0; i < 4; ++i) {
+                const int c = refl_clamp(x0 + i, w);
+                uint32_t g;
+                if (CH == 1) g = s[c];
+                else g = (s[3 * c] * 4899u + s[3 * c + 1] * 9617u + s[3 * c + 2] * 1868u + 8192u) >> 14;
+                v |= g << (8 * i);
+            }
         }
+        *(uint32_t*)(d + 4 * q) = v;           // rows are 4-B aligned with >= 64 B of slack on both sides
     }
-    *(uint32_t*)d = v;           // rows are 4-B aligned with >= 64 B of slack on both sides
 }
 
 void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
                       uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s)
 {
-    const int gx = (w + 2 * kPadX + 255) / 256, bpf = gx * ((h + 3) / 4);
+    const int bpf = (h + 3) / 4;
     const int aligned4 = ((uintptr_t)src % 4 == 0) && (stride % 4 == 0) && (frameStride % 4 == 0);
     hipLaunchKernelGGL(k_level0<1>, dim3(bpf * batch), dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, aligned4, zeroA, nA, zeroB, nB,
-                       gx, bpf, batch);
+                       bpf, batch);
 }
 void launch_rgb2gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
                      uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s)
 {
-    const int gx = (w + 2 * kPadX + 255) / 256, bpf = gx * ((h + 3) / 4);
+    const int bpf = (h + 3) / 4;
     hipLaunchKernelGGL(k_level0<3>, dim3(bpf * batch), dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, 0, zeroA, nA, zeroB, nB,
-                       gx, bpf, batch);
+                       bpf, batch);
 }
 
 // ---------------------------------------------------------------------------

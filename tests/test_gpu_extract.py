@@ -102,6 +102,22 @@ def test_batch_equals_singles_and_stream(mods):
     g.close()
 
 
+def test_batch_of_eleven_mixes_both_workgroup_orders(mods):
+    """frames 0..7 take the frame -> XCD workgroup order, frames 8..10 the plain one (xcd_frame_block); small frames so
+    that the short FAST tiles are used, then a batch large enough for the tall ones"""
+    S, synth, O = mods
+    for (w, h, nb, nf) in ((320, 240, 11, 500), (640, 480, 19, 1000)):
+        frames = synth.frame_stream(77, nb, h, w)
+        g = S.ORBextractor(nf, 1.2, 8, 20, 7); c = O.Extractor(nf, 1.2, 8, 20, 7)
+        kps, desc, n = g.extract_batch(frames)
+        for f in range(nb):
+            rk, rd = c.extract(frames[f])
+            assert n[f] == len(rk), f
+            assert np.array_equal(kps[f, :n[f]].view(np.uint8), rk.view(np.uint8)), "frame %d keypoints" % f
+            assert np.array_equal(desc[f, :n[f]], rd), "frame %d descriptors" % f
+        g.close()
+
+
 def test_pipelined_extract_and_match_on_one_stream(mods):
     """ssvio_orb_extract_batch_dev_async + a matcher bound to the extractor's stream: several steps are enqueued with no
     host wait in between; what is fetched afterwards equals the waiting calls' results and the oracle's matches"""
