@@ -77,7 +77,7 @@ def algorithmic_bytes(kernel, B, px, nkp_total, pairs_rows):
     return 0
 
 
-def cpu_baseline(frames, nfeatures, budget_s=12.0):
+def cpu_baseline(frames, nfeatures, match_mode="bf", budget_s=12.0):
     """oracle extract + BF match vs previous frame, 1 thread, bounded sample of the same frames"""
     from oracle import oracle as O
     ex = O.Extractor(nfeatures, 1.2, 8, 20, 7)
@@ -88,14 +88,15 @@ def cpu_baseline(frames, nfeatures, budget_s=12.0):
         f = frames[n % len(frames)]
         k, d = ex.extract(f)
         if prev is not None:
-            O.match_bruteforce(d, prev)
+            {"bf": O.match_bruteforce, "ratio": O.match_knn2_ratio, "crosscheck": O.match_crosscheck}[match_mode](d, prev)
         prev = d
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= 8 * len(frames):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d VGA frames (extract %d features + BF match vs previous), oracle C restatement, 1 thread, %.1f s" % (n, nfeatures, dt)}
+            "sample": "%d frames of %dx%d (extract %d features + %s match vs previous), oracle C restatement, 1 thread, %.1f s"
+                      % (n, frames.shape[2], frames.shape[1], nfeatures, match_mode, dt)}
 
 
 class _DevBytes:
@@ -215,6 +216,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--features", type=int, default=1000)
+    ap.add_argument("--match-mode", choices=["bf", "ratio", "crosscheck"], default="bf",
+                    help="bf = MatchByBruteForce (config 2); ratio = kNN2 + Threshold/NNRatio (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched-matching", action="store_true", help="skip the configs[3]/[4] matching section")
     ap.add_argument("--sync-steps", action="store_true", help="host waits for every step (latency mode)")
@@ -260,6 +263,7 @@ def main():
     # stream and the host does not wait inside a step; --sync-steps restores one host wait per step
     for e, m in zip(exs, fms):
         m.set_stream(e.get_stream())
+    mode = {"bf": L.MODE_BRUTEFORCE, "ratio": L.MODE_KNN2_RATIO, "crosscheck": L.MODE_CROSSCHECK}[args.match_mode]
     nstep = [0]
     inflight = [S]
 
@@ -268,7 +272,7 @@ def main():
         nstep[0] += 1
         e.extract_batch_dev(d_frames, B, W, H, wait=args.sync_steps)
         d_kp, d_desc, d_n, cap = e.device_results()
-        m.match_batch_dev(d_desc, cap, cap, d_n, pairs, L.MODE_BRUTEFORCE)
+        m.match_batch_dev(d_desc, cap, cap, d_n, pairs, mode)
         if args.sync_steps:
             m.sync()
 
@@ -381,7 +385,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: VGA %dx%d stream, %d features/frame, 8 levels, extract + MatchByBruteForce vs previous frame" % (W, H, args.features),
+            "config": {"workload": "%s: %dx%d stream, %d features/frame, 8 levels, extract + %s vs previous frame"
+                                   % ("configs[1]" if (W, H, args.features, args.match_mode) == (640, 480, 1000, "bf") else "configs[2]" if (W, H, args.features, args.match_mode) == (1920, 1080, 4000, "ratio") else "custom",
+                                      W, H, args.features, {"bf": "MatchByBruteForce", "ratio": "kNN2 ratio test", "crosscheck": "cross-check"}[args.match_mode]),
                        "frames_per_step": B, "parallelism": "frames sharded over %d rank(s), replicas, no collective on the data path" % world,
                        "steps_in_flight": S},
             "keypoints_per_frame": round(float(counts.mean()), 1),
@@ -394,7 +400,7 @@ def main():
             "batched_matching": bm,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, args.features)
+            out["cpu_baseline"] = cpu_baseline(frames, args.features, args.match_mode)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
