@@ -44,6 +44,30 @@ public:
         status_ = SSVIO_ERR_INVALID;
         return false;
     }
+    // include/FeatureMatching.h:30-32, src/FeatureMatching.cpp:128-189; K, R 3x3 and t 3x1 are CV_64F like the reference's
+    bool MatchByProject(std::vector<cv::Point3d>& vp3d1, cv::Mat& desp1, std::vector<cv::Point2d>& vp2d2, cv::Mat& desp2,
+                        double& radian, cv::Mat& K, cv::Mat& R, cv::Mat& t, std::vector<cv::DMatch>& matches)
+    {
+        matches.clear();                                              // :132
+        status_ = SSVIO_OK;
+        if (vp3d1.empty()) return false;
+        if ((int)vp3d1.size() != desp1.rows || (int)vp2d2.size() != desp2.rows || desp1.cols != 32 || (desp2.rows > 0 && desp2.cols != 32)) {
+            status_ = SSVIO_ERR_INVALID; return false;
+        }
+        static_assert(sizeof(cv::Point3d) == 24 && sizeof(cv::Point2d) == 16, "cv::Point3d / Point2d layout");
+        double k[9], r[9], tr[3];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) { k[3 * i + j] = K.at<double>(i, j); r[3 * i + j] = R.at<double>(i, j); }
+            tr[i] = t.at<double>(i, 0);
+        }
+        matches.resize(vp3d1.size());
+        int n = 0;
+        status_ = ssvio_match_project(m_, &vp3d1[0].x, desp1.ptr(0), desp1.rows, (int)desp1.step,
+                                      vp2d2.empty() ? nullptr : &vp2d2[0].x, desp2.rows > 0 ? desp2.ptr(0) : nullptr, desp2.rows, (int)desp2.step,
+                                      radian, k, r, tr, (ssvio_dmatch*)matches.data(), (int)matches.size(), &n);
+        matches.resize(status_ == SSVIO_OK ? n : 0);
+        return matches.size() > 0;                                    // :188
+    }
     int lastStatus() const { return status_; }
     ssvio_matcher* handle() { return m_; }
 

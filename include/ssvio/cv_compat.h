@@ -1,7 +1,7 @@
 // cv_compat.h -- the few cv:: types the adapters touch.
 // With -DSSVIO_HAVE_OPENCV the real OpenCV headers are used and SSVIO's other sources compile
 // unchanged against the adapters.  Without OpenCV (this build image has none) a minimal set of
-// layout-compatible PODs (KeyPoint 28 B, DMatch 16 B, a ref-counted 8-bit Mat) keeps the adapters
+// layout-compatible PODs (KeyPoint 28 B, DMatch 16 B, Point2d/3d, a ref-counted 8-bit / 64F Mat) keeps the adapters
 // compilable and testable.  This is NOT an OpenCV replacement and is not used to build the reference.
 #pragma once
 #ifdef SSVIO_HAVE_OPENCV
@@ -18,8 +18,11 @@ enum { CV_8UC1_ = 0, CV_8UC3_ = 16 };
 #define CV_8U 0
 #define CV_8UC1 0
 #define CV_8UC3 16
+#define CV_64F 6
 #endif
 struct Point2f { float x, y; Point2f(float x_ = 0, float y_ = 0) : x(x_), y(y_) {} };
+struct Point2d { double x, y; Point2d(double x_ = 0, double y_ = 0) : x(x_), y(y_) {} };
+struct Point3d { double x, y, z; Point3d(double x_ = 0, double y_ = 0, double z_ = 0) : x(x_), y(y_), z(z_) {} };
 struct KeyPoint {
     Point2f pt; float size, angle, response; int octave, class_id;
     KeyPoint() : pt(0, 0), size(0), angle(-1), response(0), octave(0), class_id(-1) {}
@@ -37,7 +40,7 @@ public:
     Mat(int r, int c, int type, void* ext, size_t step_) : rows(r), cols(c), step(step_), data((unsigned char*)ext), type_(type) {}
     void create(int r, int c, int type) {
         if (r == rows && c == cols && type == type_ && data && buf_) return;
-        rows = r; cols = c; type_ = type; step = (size_t)c * channels();
+        rows = r; cols = c; type_ = type; step = (size_t)c * elemSize();
         buf_.reset(new unsigned char[(size_t)(r > 0 ? r : 0) * step + 1], std::default_delete<unsigned char[]>());
         data = buf_.get();
     }
@@ -45,7 +48,9 @@ public:
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     int type() const { return type_; }
     int channels() const { return type_ == CV_8UC3 ? 3 : 1; }
-    bool isContinuous() const { return step == (size_t)cols * channels(); }
+    size_t elemSize() const { return type_ == CV_64F ? 8 : (size_t)channels(); }
+    bool isContinuous() const { return step == (size_t)cols * elemSize(); }
+    template <class T> T& at(int r, int c = 0) { return *(T*)(data + (size_t)r * step + (size_t)c * sizeof(T)); }
     unsigned char* ptr(int r = 0) { return data + (size_t)r * step; }
     const unsigned char* ptr(int r = 0) const { return data + (size_t)r * step; }
     Mat getMat() const { return *this; }

@@ -170,6 +170,16 @@ int  ssvio_match_crosscheck(ssvio_matcher* m, const uint8_t* q, int nq, int qstr
 int  ssvio_match_knn2_raw(ssvio_matcher* m, const uint8_t* q, int nq, int qstride,
                           const uint8_t* t, int nt, int tstride, int32_t* idx, int32_t* d1, int32_t* d2);
 
+/* FeatureMatching::MatchByProject(vp3d1, desp1, vp2d2, desp2, radian, K, R, t, matches), include/FeatureMatching.h:30-32,
+ * src/FeatureMatching.cpp:128-189 (the DBoW3-free half): reference point i (p3d[i][3], descriptor row i
+ * of q) is projected with R, t, K (row-major 3x3 / 3 doubles, the reference's double arithmetic incl. its bounds test
+ * against the principal point, :141); among the train keypoints p2d[j][2] strictly inside the +-radian window the best /
+ * second-best Hamming distances decide: kept iff best < Threshold and best < NNRatio * second (:177-178).
+ * out[cap >= nq] receives DMatch{queryIdx = i, trainIdx, imgIdx = -1, distance} in ascending i. */
+int  ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, int nq, int qstride,
+                         const double* p2d, const uint8_t* t, int nt, int tstride, double radian,
+                         const double* K, const double* R, const double* tr, ssvio_dmatch* out, int cap, int* n);
+
 /* Batched matching over descriptor sets resident in HBM (BASELINE configs 2, 4, 5).
  * d_desc: set s occupies rows [s*set_stride_rows, +counts[s]) of a contiguous [rows][32] byte array.
  * d_counts: int32 per set (device).  pairs: host array of npairs (query_set, train_set) int32 pairs.

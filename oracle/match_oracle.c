@@ -4,6 +4,7 @@
  *   :211-228 ComputeMatchingScore   -> orc_hamming256
  *   :85-112  2-NN + Threshold/NNRatio acceptance -> orc_knn2_raw / orc_match_knn2_ratio
  *   :20-55   MatchByBruteForce      -> orc_match_bruteforce (BFMatcher per SURVEY App. A6)
+ *   :128-189 MatchByProject         -> orc_match_project (the DBoW3-free half)
  * Cross-check has no reference code; mutual nearest neighbour as defined in App. A6.
  */
 #include "ssvio_oracle.h"
@@ -106,5 +107,45 @@ int orc_match_crosscheck(const uint8_t* q, int nq, int qstride, const uint8_t* t
     for (int i = 0; i < nq; ++i)
         if (qi[i] >= 0 && ti[qi[i]] == i) { out[n].queryIdx = i; out[n].trainIdx = qi[i]; out[n].imgIdx = 0; out[n].distance = (float)qd[i]; ++n; }
     free(qi); free(qd); free(ti); free(td);
+    return n;
+}
+
+/* MatchByProject, src/FeatureMatching.cpp:128-189.  p3d[n1][3], p2d[n2][2], K/R row-major 3x3, t[3], all double.
+ * OpenCV arithmetic behind the cv::Mat expressions (canonical choices, unverifiable here like the rest):
+ *   R*p3d + t      one gemm with C = t: (r0*x + r1*y + r2*z) summed left to right, then + t, no contraction (:137)
+ *   p /= p(2,0)    Mat::operator/=(double) is convertTo(alpha = 1./s): every element is MULTIPLIED by (1.0 / z) (:138)
+ * The bounds test against K(0,2) / K(1,2) (the principal point, not the image size) is the reference's (:141). */
+int orc_match_project(const double* p3d, const uint8_t* q, int n1, int qstride,
+                      const double* p2d, const uint8_t* t, int n2, int tstride,
+                      double radian, const double* K, const double* R, const double* tr,
+                      int threshold, float nn_ratio, orc_dmatch* out)
+{
+    int n = 0;
+    for (int i = 0; i < n1; ++i) {
+        const double x = p3d[3 * i], y = p3d[3 * i + 1], z = p3d[3 * i + 2];
+        double px = R[0] * x + R[1] * y + R[2] * z + tr[0];                   /* :137 */
+        double py = R[3] * x + R[4] * y + R[5] * z + tr[1];
+        const double pz = R[6] * x + R[7] * y + R[8] * z + tr[2];
+        const double inv = 1. / pz;                                             /* :138 */
+        px = px * inv; py = py * inv;
+        const double u = K[0] * px + K[2];                                      /* :139 */
+        const double v = K[4] * py + K[5];                                      /* :140 */
+        if (u < 0 || u > K[2] || v < 0 || v > K[5]) continue;                   /* :141 (also drops NaN-free out-of-range only) */
+        int min_dist = 256, sec_min_dist = 256, best_id = -1;                   /* :160-162 */
+        for (int j = 0; j < n2; ++j) {
+            const double x2 = p2d[2 * j], y2 = p2d[2 * j + 1];
+            if ((u - radian) < x2 && (u + radian) > x2 && (v - radian) < y2 && (v + radian) > y2) {   /* :151-152 */
+                const int dist = orc_hamming256(q + (size_t)i * qstride, t + (size_t)j * tstride);
+                if (dist < min_dist) { sec_min_dist = min_dist; min_dist = dist; best_id = j; }
+                else if (dist < sec_min_dist) sec_min_dist = dist;
+            }
+        }
+        if (min_dist < threshold) {                                             /* :177 (strict, unlike :104) */
+            if ((float)min_dist < nn_ratio * (float)sec_min_dist) {             /* :178 */
+                orc_dmatch m; m.queryIdx = i; m.trainIdx = best_id; m.imgIdx = -1; m.distance = (float)min_dist;
+                out[n++] = m;
+            }
+        }
+    }
     return n;
 }

@@ -297,6 +297,22 @@ def match_knn2_ratio(q, t, threshold=50, nn_ratio=0.6):
     return out[:n].copy()
 
 
+def match_project(p3d, q, p2d, t, radian, K, R, tr, threshold=50, nn_ratio=0.6):
+    """src/FeatureMatching.cpp:128-189"""
+    q = _desc(q); t = _desc(t)
+    p3d = np.ascontiguousarray(p3d, np.float64).reshape(-1, 3); p2d = np.ascontiguousarray(p2d, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64).reshape(9); R = np.ascontiguousarray(R, np.float64).reshape(9)
+    tr = np.ascontiguousarray(tr, np.float64).reshape(3)
+    assert len(p3d) == len(q) and len(p2d) == len(t)
+    out = np.zeros(max(len(q), 1), DM_DTYPE)
+    f = lib().orc_match_project
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    n = f(_p(p3d), _p(q), len(q), 32, _p(p2d), _p(t), len(t), 32, float(radian), _p(K), _p(R), _p(tr), threshold, nn_ratio, _p(out))
+    return out[:n].copy()
+
+
 def match_crosscheck(q, t):
     q = _desc(q); t = _desc(t)
     out = np.zeros(max(len(q), 1), DM_DTYPE)

@@ -86,6 +86,11 @@ int  orc_match_knn2_ratio(const uint8_t* q, int nq, int qstride, const uint8_t* 
                           int threshold, float nn_ratio, orc_dmatch* out);             /* :85-112 over all rows */
 int  orc_match_crosscheck(const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
                           orc_dmatch* out);                                            /* App. A6 mutual-NN */
+/* MatchByProject (:128-189): project p3d with R, t, K; 2-NN among the train keypoints inside the +-radian window */
+int  orc_match_project(const double* p3d, const uint8_t* q, int n1, int qstride,
+                       const double* p2d, const uint8_t* t, int n2, int tstride,
+                       double radian, const double* K, const double* R, const double* tr,
+                       int threshold, float nn_ratio, orc_dmatch* out);
 #ifdef __cplusplus
 }
 #endif

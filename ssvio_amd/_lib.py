@@ -57,6 +57,7 @@ SYMBOLS = {
     "ssvio_distribute_octtree": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "ssvio_orb_set_profiling": (_i, [_vp, _i]),
     "ssvio_orb_kernel_times": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "ssvio_match_project": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp, _vp, _vp, _i, _vp]),
     "ssvio_orb_profile_only": (_i, [_vp, C.c_char_p]),
     "ssvio_matcher_profile_only": (_i, [_vp, C.c_char_p]),
     "ssvio_orb_set_stream": (_i, [_vp, _vp]),

@@ -752,6 +752,8 @@ struct ssvio_matcher {
     int32_t* d_raw = nullptr; size_t rawCap = 0;
     int* d_nout = nullptr; size_t noutCap = 0;
     int* d_pairs = nullptr; size_t pairsCap = 0;
+    double* d_p3d = nullptr; size_t p3dCap = 0; double* d_p2d = nullptr; size_t p2dCap = 0;     // MatchByProject inputs
+    ssvio_dmatch* d_cand = nullptr; size_t candCap = 0; int* d_keep = nullptr; size_t keepCap = 0;
     std::vector<int32_t> h_pairs;                     // what d_pairs holds (an unchanged pair list is not uploaded again)
     KernelProfiler prof; std::string profOnly;
     int lastPairs = 0, lastMaxRows = 0;
@@ -901,6 +903,7 @@ void ssvio_matcher_destroy(ssvio_matcher* m)
     m->prof.resolve(); m->prof.destroy();
     dfree(m->d_q); dfree(m->d_t); dfree(m->d_counts2); dfree(m->d_partial); dfree(m->d_partialRev);
     dfree(m->d_out); dfree(m->d_raw); dfree(m->d_nout); dfree(m->d_pairs);
+    dfree(m->d_p3d); dfree(m->d_p2d); dfree(m->d_cand); dfree(m->d_keep);
     if (m->own) (void)hipStreamDestroy(m->own);
     delete m;
 }
@@ -955,6 +958,55 @@ int ssvio_match_crosscheck(ssvio_matcher* m, const uint8_t* q, int nq, int qstri
 int ssvio_match_knn2_raw(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
                          int32_t* idx, int32_t* d1, int32_t* d2)
 { return match_host(m, q, nq, qstride, t, nt, tstride, 3, nullptr, 0, nullptr, idx, d1, d2); }
+
+int ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, int nq, int qstride,
+                        const double* p2d, const uint8_t* t, int nt, int tstride, double radian,
+                        const double* K, const double* R, const double* tr, ssvio_dmatch* out, int cap, int* n)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (n) *n = 0;
+    if (nq < 0 || nt < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (nq == 0) return SSVIO_OK;                                   // the loop of src/FeatureMatching.cpp:135 does not run
+    if (!p3d || !q || !K || !R || !tr || !n || (nt > 0 && (!p2d || !t))) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    if (qstride < 32 || (nt > 0 && tstride < 32)) { set_error("descriptor stride < 32"); return SSVIO_ERR_INVALID; }
+    if (nt > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
+    if (cap < nq) { set_error("output capacity %d < %d reference points", cap, nq); return SSVIO_ERR_CAPACITY; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
+    int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
+    rc = grow(m->d_t, tcap, (size_t)std::max(nt, 1) * 32, s); if (rc) return rc; m->tRows = tcap / 32;
+    rc = grow(m->d_p3d, m->p3dCap, (size_t)nq * 3, s); if (rc) return rc;
+    rc = grow(m->d_p2d, m->p2dCap, (size_t)std::max(nt, 1) * 2, s); if (rc) return rc;
+    rc = grow(m->d_cand, m->candCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_keep, m->keepCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_out, m->outCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
+    SSVIO_HIP(hipMemcpy2DAsync(m->d_q, 32, q, qstride, 32, nq, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(m->d_p3d, p3d, (size_t)nq * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (nt > 0) {
+        SSVIO_HIP(hipMemcpy2DAsync(m->d_t, 32, t, tstride, 32, nt, hipMemcpyHostToDevice, s));
+        SSVIO_HIP(hipMemcpyAsync(m->d_p2d, p2d, (size_t)nt * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    ProjectArgs a{};
+    a.p3d = m->d_p3d; a.qdesc = (const uint4*)m->d_q; a.nq = nq; a.p2d = m->d_p2d; a.tdesc = (const uint4*)m->d_t; a.nt = nt;
+    a.radian = radian;
+    for (int i = 0; i < 9; ++i) { a.K[i] = K[i]; a.R[i] = R[i]; }
+    for (int i = 0; i < 3; ++i) a.t[i] = tr[i];
+    a.threshold = m->threshold; a.nnRatio = m->nnRatio;
+    a.cand = m->d_cand; a.keep = m->d_keep; a.out = m->d_out; a.nout = m->d_nout;
+    {
+        ProfScope p(m->prof, "k_match_project", s);
+        launch_project(a, s);
+    }
+    int cnt = 0;
+    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+    *n = cnt;
+    m->prof.resolve();
+    return SSVIO_OK;
+}
 
 int ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_rows, int max_rows, const int32_t* d_counts,
                           const int32_t* pairs, int npairs, int mode, const void** d_matches, const int32_t** d_nmatches)

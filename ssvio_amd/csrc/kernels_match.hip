@@ -249,6 +249,76 @@ __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
     if (tid == 0) a.nout[pair] = written;
 }
 
+// ---------------------------------------------------------------------------
+// MatchByProject (src/FeatureMatching.cpp:128-189): one wave per reference point.  The projection is the reference's
+// double sequence (no contraction: this file is compiled with -ffp-contract=off); the lanes walk the train keypoints,
+// test the +-radian window, and keep the two smallest keys (dist << 23 | j) of those inside, which a wave-wide
+// shuffle reduction merges: smallest key = first minimal distance in ascending j (:166-170), second = sec_min_dist.
+__global__ __launch_bounds__(256) void k_match_project(ProjectArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.nq) return;                                               // wave-uniform
+    const double x = a.p3d[3 * i], y = a.p3d[3 * i + 1], z = a.p3d[3 * i + 2];
+    double px = a.R[0] * x + a.R[1] * y + a.R[2] * z + a.t[0];           // :137
+    double py = a.R[3] * x + a.R[4] * y + a.R[5] * z + a.t[1];
+    const double pz = a.R[6] * x + a.R[7] * y + a.R[8] * z + a.t[2];
+    const double inv = 1. / pz;                                          // :138, Mat /= s multiplies by 1./s
+    px = px * inv; py = py * inv;
+    const double u = a.K[0] * px + a.K[2], v = a.K[4] * py + a.K[5];     // :139-140
+    const bool inside = !(u < 0 || u > a.K[2] || v < 0 || v > a.K[5]);   // :141
+    uint32_t k1 = kKeyInit, k2 = kKeyInit;
+    if (inside) {
+        const uint4 qlo = a.qdesc[2 * (size_t)i], qhi = a.qdesc[2 * (size_t)i + 1];
+        const double ulo = u - a.radian, uhi = u + a.radian, vlo = v - a.radian, vhi = v + a.radian;
+        for (int j = lane; j < a.nt; j += 64) {
+            const double x2 = a.p2d[2 * j], y2 = a.p2d[2 * j + 1];
+            if (ulo < x2 && uhi > x2 && vlo < y2 && vhi > y2) {          // :151-152
+                const uint4 lo = a.tdesc[2 * (size_t)j], hi = a.tdesc[2 * (size_t)j + 1];
+                const uint32_t d = __popc(qlo.x ^ lo.x) + __popc(qlo.y ^ lo.y) + __popc(qlo.z ^ lo.z) + __popc(qlo.w ^ lo.w) +
+                                   __popc(qhi.x ^ hi.x) + __popc(qhi.y ^ hi.y) + __popc(qhi.z ^ hi.z) + __popc(qhi.w ^ hi.w);
+                const uint32_t key = (d << 23) | (uint32_t)j;
+                k2 = umed3(k1, k2, key); k1 = min(k1, key);
+            }
+        }
+    }
+    // wavefront-shuffle argmin: merge the lanes' (smallest, second smallest) pairs
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
+        const uint32_t lo1 = min(k1, o1), hi1 = max(k1, o1);
+        k2 = min(hi1, min(k2, o2)); k1 = lo1;
+    }
+    if (lane == 0) {
+        const int minDist = min((int)(k1 >> 23), 256), secDist = min((int)(k2 >> 23), 256);
+        const bool keep = inside && minDist < a.threshold && (float)minDist < a.nnRatio * (float)secDist;   // :177-178
+        ssvio_dmatch m; m.queryIdx = i; m.trainIdx = (int)(k1 & 0x7FFFFF); m.imgIdx = -1; m.distance = (float)minDist;
+        a.cand[i] = m; a.keep[i] = keep ? 1 : 0;
+    }
+}
+
+// matches in ascending reference-point order (the reference's push_back order)
+__global__ __launch_bounds__(256) void k_project_compact(ProjectArgs a)
+{
+    __shared__ int wsum[4];
+    int written = 0;
+    for (int i0 = 0; i0 < a.nq; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const bool keep = i < a.nq && a.keep[i];
+        int total;
+        const int off = block_excl_scan(keep ? 1 : 0, wsum, total);
+        if (keep) a.out[written + off] = a.cand[i];
+        written += total;
+    }
+    if (threadIdx.x == 0) *a.nout = written;
+}
+
+void launch_project(const ProjectArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_match_project, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_project_compact, dim3(1), dim3(256), 0, s, a);
+}
+
 void launch_finalize(const FinalizeArgs& a0, int npairs, int maxQ, int maxT, hipStream_t s)
 {
     FinalizeArgs a = a0;

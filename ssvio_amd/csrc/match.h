@@ -26,6 +26,17 @@ struct FinalizeArgs {
     int32_t* raw;                               // mode 3: [pair][3][maxRows]
 };
 
+// MatchByProject (src/FeatureMatching.cpp:128-189)
+struct ProjectArgs {
+    const double* p3d; const uint4* qdesc; int nq;      // [nq][3], [nq][2] uint4
+    const double* p2d; const uint4* tdesc; int nt;      // [nt][2], [nt][2] uint4
+    double radian, K[9], R[9], t[3];
+    int threshold; float nnRatio;
+    ssvio_dmatch* cand; int* keep;                      // per query: the match it would emit, and whether it does
+    ssvio_dmatch* out; int* nout;
+};
+void launch_project(const ProjectArgs& a, hipStream_t s);
+
 void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, int npairs, int maxQ, int maxT, hipStream_t s);
 

@@ -57,6 +57,20 @@ class FeatureMatching:
         m = self._call(L.lib().ssvio_match_crosscheck, desp1, desp2)
         return len(m) > 0, m
 
+    def MatchByProject(self, vp3d1, desp1, vp2d2, desp2, radian, K, R, t):
+        """include/FeatureMatching.h:30-32, src/FeatureMatching.cpp:128-189: vp3d1 [n1][3] reference points with
+        descriptors desp1, vp2d2 [n2][2] keypoints with descriptors desp2, K / R 3x3, t 3 (float64)"""
+        q, nq, qs = self._rows(desp1); tt, nt, ts = self._rows(desp2)
+        p3 = np.ascontiguousarray(vp3d1, np.float64).reshape(-1, 3); p2 = np.ascontiguousarray(vp2d2, np.float64).reshape(-1, 2)
+        assert len(p3) == nq and len(p2) == nt, "one point per descriptor row"
+        K = np.ascontiguousarray(K, np.float64).reshape(9); R = np.ascontiguousarray(R, np.float64).reshape(9)
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        out = np.zeros(max(nq, 1), L.DM_DTYPE); n = C.c_int(0)
+        L.check(L.lib().ssvio_match_project(self._h, L.ptr(p3), L.ptr(q), nq, qs, L.ptr(p2), L.ptr(tt), nt, ts, float(radian),
+                                            L.ptr(K), L.ptr(R), L.ptr(t), L.ptr(out), max(nq, 1), C.byref(n)))
+        m = out[:n.value].copy()
+        return len(m) > 0, m
+
     def MatchByDBoW(self, desp1, desp2):
         """include/FeatureMatching.h:27: needs the DBoW3 vocabulary (un-vendored library, blob
         missing from the reference tree) -- out of scope, never silently emulated."""

@@ -41,13 +41,32 @@ int main(int argc, char** argv)
         cv::Mat e; std::vector<cv::DMatch> m3; m3.resize(3);
         const bool okEmpty = fm->MatchByBruteForce(e, da, m3);
         if (okEmpty || !m3.empty()) { fprintf(stderr, "empty-input contract broken\n"); return 1; }
+        // MatchByProject the way Odometry would call it: frame A's keypoints back-projected at made-up depths, frame B's
+        // keypoints as 2-D candidates (include/FeatureMatching.h:30-32)
+        std::vector<cv::Point3d> p3; std::vector<cv::Point2d> p2;
+        const double fx = 260.0, fy = 260.0, cx = w / 2.0, cy = h / 2.0;
+        for (size_t i = 0; i < ka.size(); ++i) {
+            const double d = 1.0 + 0.5 * (double)(i % 7);
+            p3.push_back(cv::Point3d((ka[i].pt.x - cx) / fx * d, (ka[i].pt.y - cy) / fy * d, d));
+        }
+        for (size_t i = 0; i < kb.size(); ++i) p2.push_back(cv::Point2d(kb[i].pt.x, kb[i].pt.y));
+        cv::Mat K(3, 3, CV_64F), R(3, 3, CV_64F), t(3, 1, CV_64F);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { K.at<double>(i, j) = 0; R.at<double>(i, j) = i == j ? 1.0 : 0.0; }
+        K.at<double>(0, 0) = fx; K.at<double>(1, 1) = fy; K.at<double>(0, 2) = cx; K.at<double>(1, 2) = cy; K.at<double>(2, 2) = 1.0;
+        t.at<double>(0, 0) = 0.02; t.at<double>(1, 0) = -0.01; t.at<double>(2, 0) = 0.0;
+        double radian = 12.0;
+        std::vector<cv::DMatch> m4;
+        fm->MatchByProject(p3, da, p2, db, radian, K, R, t, m4);
+        if (fm->lastStatus() != SSVIO_OK) { fprintf(stderr, "MatchByProject: %s\n", ssvio_last_error()); return 1; }
+        dump((out + ".p3").c_str(), p3.data(), p3.size() * sizeof(cv::Point3d));
+        dump((out + ".m4").c_str(), m4.data(), m4.size() * sizeof(cv::DMatch));
         dump((out + ".ka").c_str(), ka.data(), ka.size() * sizeof(cv::KeyPoint));
         dump((out + ".kb").c_str(), kb.data(), kb.size() * sizeof(cv::KeyPoint));
         dump((out + ".da").c_str(), da.data, (size_t)da.rows * 32);
         dump((out + ".db").c_str(), db.data, (size_t)db.rows * 32);
         dump((out + ".m").c_str(), m.data(), m.size() * sizeof(cv::DMatch));
         dump((out + ".m2").c_str(), m2.data(), m2.size() * sizeof(cv::DMatch));
-        printf("ok=%d ka=%zu kb=%zu m=%zu m2=%zu levels=%d pyr0=%dx%d\n", (int)ok, ka.size(), kb.size(), m.size(), m2.size(),
+        printf("ok=%d ka=%zu kb=%zu m=%zu m2=%zu m4=%zu levels=%d pyr0=%dx%d\n", (int)ok, ka.size(), kb.size(), m.size(), m2.size(), m4.size(),
                orb->GetLevels(), orb->mvImagePyramid[0].cols, orb->mvImagePyramid[0].rows);
     } catch (const std::exception& ex) {
         fprintf(stderr, "exception: %s\n", ex.what());

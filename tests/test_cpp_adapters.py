@@ -33,3 +33,9 @@ def test_adapters_match_oracle(tmp_path):
     assert rd(".da") == da.tobytes() and rd(".db") == db.tobytes()
     assert rd(".m") == O.match_bruteforce(db, da).tobytes()
     assert rd(".m2") == O.match_knn2_ratio(db, da, 50, 0.6).tobytes()
+    # MatchByProject with the inputs the adapter test built (reference points dumped by it)
+    p3 = np.frombuffer(rd(".p3"), np.float64).reshape(-1, 3)
+    K = np.array([[260.0, 0, 160.0], [0, 260.0, 120.0], [0, 0, 1.0]]); R = np.eye(3); t = np.array([0.02, -0.01, 0.0])
+    p2 = np.stack([kb["x"].astype(np.float64), kb["y"].astype(np.float64)], 1)
+    want = O.match_project(p3, da, p2, db, 12.0, K, R, t, 50, 0.6)
+    assert rd(".m4") == want.tobytes() and len(want) > 10

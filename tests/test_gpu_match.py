@@ -105,3 +105,44 @@ def test_match_real_descriptors_frame_pair(mods, fm):
     assert ok and np.array_equal(m.view(np.uint8), O.match_bruteforce(db, da).view(np.uint8))
     assert len(m) > 50
     g.close()
+
+
+def _project_scene(seed, n1, n2, synth):
+    rng = np.random.default_rng(seed)
+    K = np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1.0]])
+    p2 = np.stack([rng.uniform(0, 640, n2), rng.uniform(0, 480, n2)], 1)
+    src = rng.integers(0, n2, n1)
+    depth = rng.uniform(0.5, 6.0, n1)
+    a, b = 0.02, -0.015
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1.0, 0], [-np.sin(b), 0, np.cos(b)]])
+    R = Rz @ Ry; t = np.array([0.03, -0.01, 0.05])
+    cam = np.stack([(p2[src, 0] - 319.5) / 525 * depth, (p2[src, 1] - 239.5) / 525 * depth, depth], 1)
+    cam += rng.normal(0, 0.004, cam.shape) * depth[:, None]
+    P3 = (cam - t) @ R
+    dq, dt = synth.descriptor_sets(seed, n1, n2)
+    dq = dt[src].copy(); flips = rng.random((n1, 256)) < 0.06
+    dq ^= np.packbits(flips, axis=1, bitorder="little")
+    return P3, dq, p2, dt, K, R, t
+
+
+@pytest.mark.parametrize("n1,n2,radian", [(1, 1, 5.0), (300, 500, 8.0), (1000, 1000, 15.0), (4000, 4000, 25.0), (257, 3, 1000.0)])
+def test_match_by_project_equals_oracle(mods, fm, n1, n2, radian):
+    """MatchByProject (src/FeatureMatching.cpp:128-189): the projection runs the same IEEE double sequence on both sides,
+    so the candidate windows, indices and distances are bit-exact"""
+    S, synth, O = mods
+    P3, dq, p2, dt, K, R, t = _project_scene(n1 * 7 + n2, n1, n2, synth)
+    ok, m = fm.MatchByProject(P3, dq, p2, dt, radian, K, R, t)
+    want = O.match_project(P3, dq, p2, dt, radian, K, R, t, 50, 0.6)
+    assert np.array_equal(m.view(np.uint8), want.view(np.uint8)) and ok == (len(want) > 0)
+    if n1 >= 300:
+        assert len(want) > n1 // 20                     # the scene is not degenerate
+
+
+def test_match_by_project_empty_inputs(mods, fm):
+    S, synth, O = mods
+    P3, dq, p2, dt, K, R, t = _project_scene(5, 10, 20, synth)
+    ok, m = fm.MatchByProject(np.zeros((0, 3)), None, p2, dt, 5.0, K, R, t)
+    assert not ok and len(m) == 0
+    ok, m = fm.MatchByProject(P3, dq, np.zeros((0, 2)), None, 5.0, K, R, t)
+    assert not ok and len(m) == 0

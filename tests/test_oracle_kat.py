@@ -266,6 +266,60 @@ def test_hamming_and_bf_semantics(oracle):
     assert len(m2) == 50 and (m2["imgIdx"] == -1).all()
 
 
+def test_match_project_semantics(oracle):
+    """src/FeatureMatching.cpp:128-189 against an independent numpy restatement + hand cases"""
+    K = np.array([[500.0, 0, 320.0], [0, 500.0, 240.0], [0, 0, 1.0]]); R = np.eye(3); t = np.zeros(3)
+    z = np.zeros(32, np.uint8)
+    def bits(n):
+        b = np.zeros(256, np.uint8); b[:n] = 1
+        return np.packbits(b, bitorder="little")
+    # one reference point projecting to (100, 50); three keypoints: inside (dist 10), inside (dist 30), outside (dist 0)
+    p3d = np.array([[(100 - 320) / 500 * 2.0, (50 - 240) / 500 * 2.0, 2.0]])
+    p2d = np.array([[101.0, 51.0], [99.0, 49.0], [150.0, 50.0]])
+    q = z[None]; tt = np.stack([bits(10), bits(30), bits(0)])
+    m = oracle.match_project(p3d, q, p2d, tt, 5.0, K, R, t, 50, 0.6)
+    assert len(m) == 1 and m[0]["queryIdx"] == 0 and m[0]["trainIdx"] == 0 and m[0]["distance"] == 10.0 and m[0]["imgIdx"] == -1
+    # the window is open: a keypoint exactly radian away is not a candidate (:151-152); alone in the window, 10 < 0.6 * 256
+    m = oracle.match_project(p3d, q, np.array([[105.0, 50.0], [104.5, 50.0]]), np.stack([bits(0), bits(10)]), 5.0, K, R, t, 50, 0.6)
+    assert len(m) == 1 and m[0]["trainIdx"] == 1
+    # ratio test fails: 10 vs 16 (10 < 9.6 is false); threshold is strict: best 50 is dropped at Threshold 50 (:177)
+    assert len(oracle.match_project(p3d, q, p2d[:2], np.stack([bits(10), bits(16)]), 5.0, K, R, t, 50, 0.6)) == 0
+    assert len(oracle.match_project(p3d, q, p2d[:1], bits(50)[None], 5.0, K, R, t, 50, 0.6)) == 0
+    assert len(oracle.match_project(p3d, q, p2d[:1], bits(49)[None], 5.0, K, R, t, 50, 0.6)) == 1
+    # the bounds test uses the principal point (:141): u = 330 > cx = 320 is skipped although it is inside a 640-px image
+    far = np.array([[(330 - 320) / 500 * 2.0, (50 - 240) / 500 * 2.0, 2.0]])
+    assert len(oracle.match_project(far, q, np.array([[330.0, 50.0]]), z[None], 5.0, K, R, t, 50, 0.6)) == 0
+    # random scene vs numpy
+    rng = np.random.default_rng(11)
+    n1, n2 = 200, 300
+    p2 = np.stack([rng.uniform(0, 320, n2), rng.uniform(0, 240, n2)], 1)
+    src = rng.integers(0, n2, n1)
+    depth = rng.uniform(0.5, 4.0, n1)
+    ang = 0.01
+    Rm = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]]); tv = np.array([0.01, -0.02, 0.03])
+    cam = np.stack([(p2[src, 0] - 320) / 500 * depth, (p2[src, 1] - 240) / 500 * depth, depth], 1)
+    P3 = (cam - tv) @ Rm                                        # so that R * P3 + t lands near the source keypoint
+    dt = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    dq = dt[src].copy(); dq[:, :2] ^= rng.integers(0, 256, (n1, 2), dtype=np.uint8)
+    got = oracle.match_project(P3, dq, p2, dt, 12.0, K, Rm, tv, 50, 0.6)
+    want = []
+    for i in range(n1):
+        p = Rm @ P3[i] + tv
+        # the oracle multiplies by 1/z (Mat /= s); numpy's p / p[2] may differ in the last bit, which only matters on a window edge
+        u = 500.0 * (p[0] * (1.0 / p[2])) + 320.0; v = 500.0 * (p[1] * (1.0 / p[2])) + 240.0
+        if u < 0 or u > 320.0 or v < 0 or v > 240.0:
+            continue
+        inside = np.nonzero((u - 12.0 < p2[:, 0]) & (u + 12.0 > p2[:, 0]) & (v - 12.0 < p2[:, 1]) & (v + 12.0 > p2[:, 1]))[0]
+        if len(inside) == 0:
+            continue
+        d = np.unpackbits(dq[i][None] ^ dt[inside], axis=1).sum(1)
+        o = np.argsort(d, kind="stable")
+        best, second = int(d[o[0]]), (int(d[o[1]]) if len(o) > 1 else 256)
+        if best < 50 and np.float32(best) < np.float32(0.6) * np.float32(second):
+            want.append((i, int(inside[o[0]]), best))
+    assert [(int(m["queryIdx"]), int(m["trainIdx"]), int(m["distance"])) for m in got] == want and len(want) > 20
+
+
 def test_quadtree_small_cases(oracle):
     # one key per quadrant of a square region, N = 4: one split, list order = reverse creation (n4,n3,n2,n1)
     xs = np.array([10, 90, 10, 90], np.float32); ys = np.array([10, 10, 90, 90], np.float32); r = np.array([1, 2, 3, 4], np.float32)
