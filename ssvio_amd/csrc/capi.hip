@@ -162,6 +162,7 @@ struct ssvio_orb {
     // host copies for the host quadtree mode and the debug taps (lazily sized)
     std::vector<uint2> h_raw; std::vector<int> h_rawCount, h_cellIni; std::vector<uint2> h_sel; std::vector<int> h_selCount;
     bool hostRawValid = false;
+    std::vector<uint8_t> stageIn;      // packed copy of a strided input frame
     KernelProfiler prof; std::string profOnly;
     std::unique_ptr<WorkerPool> pool;
     int lastBatch = 0;
@@ -592,9 +593,18 @@ int ssvio_orb_extract_batch(ssvio_orb* h, const uint8_t* imgs, int batch, int ch
     int rc = orb_ensure(h, width, height, batch, (size_t)batch * rowBytes * height);
     if (rc) return rc;
     const PyramidGeom& g = h->geom;
-    for (int f = 0; f < batch; ++f)
-        SSVIO_HIP(hipMemcpy2DAsync(h->d_in + (size_t)f * rowBytes * height, rowBytes, imgs + (size_t)f * frame_stride, stride,
-                                   rowBytes, height, hipMemcpyHostToDevice, h->stream));
+    // continuous frames (the usual cv::Mat) are one copy each; strided rows (an ROI) are packed on the host first, because a
+    // 2-D copy from pageable memory costs a transfer per row
+    for (int f = 0; f < batch; ++f) {
+        const uint8_t* src = imgs + (size_t)f * frame_stride;
+        if ((size_t)stride != rowBytes) {
+            h->stageIn.resize(rowBytes * height);
+            for (int y = 0; y < height; ++y) memcpy(h->stageIn.data() + (size_t)y * rowBytes, src + (size_t)y * stride, rowBytes);
+            src = h->stageIn.data();
+        }
+        SSVIO_HIP(hipMemcpyAsync(h->d_in + (size_t)f * rowBytes * height, src, rowBytes * height, hipMemcpyHostToDevice, h->stream));
+        if ((size_t)stride != rowBytes) SSVIO_HIP(hipStreamSynchronize(h->stream));       // stageIn is reused by the next frame
+    }
     {
         ProfScope p(h->prof, channels == 3 ? "k_rgb2gray" : "k_copy_gray", h->stream);
         if (channels == 3) launch_rgb2gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
@@ -754,6 +764,7 @@ struct ssvio_matcher {
     int* d_pairs = nullptr; size_t pairsCap = 0;
     double* d_p3d = nullptr; size_t p3dCap = 0; double* d_p2d = nullptr; size_t p2dCap = 0;     // MatchByProject inputs
     ssvio_dmatch* d_cand = nullptr; size_t candCap = 0; int* d_keep = nullptr; size_t keepCap = 0;
+    std::vector<uint8_t> stageQ, stageT;              // packed copies of strided descriptor rows
     std::vector<int32_t> h_pairs;                     // what d_pairs holds (an unchanged pair list is not uploaded again)
     KernelProfiler prof; std::string profOnly;
     int lastPairs = 0, lastMaxRows = 0;
@@ -767,6 +778,18 @@ template <typename T> static int grow(T*& p, size_t& cap, size_t need, hipStream
     need += need / 4;
     SSVIO_HIP(hipMalloc(&p, need * sizeof(T)));
     cap = need;
+    return SSVIO_OK;
+}
+
+// descriptor rows host -> device.  Continuous rows (the usual cv::Mat) are one copy; strided rows are packed on the
+// host first: a 2-D copy of 32-byte rows costs a transfer per row (18 ms for 1000 rows on this stack).
+static int upload_rows(uint8_t* dst, const uint8_t* src, int n, int stride, std::vector<uint8_t>& staging, hipStream_t s)
+{
+    if (n <= 0) return SSVIO_OK;
+    if (stride == 32) { SSVIO_HIP(hipMemcpyAsync(dst, src, (size_t)n * 32, hipMemcpyHostToDevice, s)); return SSVIO_OK; }
+    staging.resize((size_t)n * 32);
+    for (int i = 0; i < n; ++i) memcpy(staging.data() + (size_t)i * 32, src + (size_t)i * stride, 32);
+    SSVIO_HIP(hipMemcpyAsync(dst, staging.data(), (size_t)n * 32, hipMemcpyHostToDevice, s));
     return SSVIO_OK;
 }
 
@@ -852,8 +875,8 @@ static int match_host(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, c
     size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
     int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
     rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
-    SSVIO_HIP(hipMemcpy2DAsync(m->d_q, 32, q, qstride, 32, nq, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipMemcpy2DAsync(m->d_t, 32, t, tstride, 32, nt, hipMemcpyHostToDevice, s));
+    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
+    rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
     const int counts[2] = {nq, nt};
     SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
     SSVIO_HIP(hipStreamSynchronize(s));                                // `counts` is a stack array
@@ -982,10 +1005,10 @@ int ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, i
     rc = grow(m->d_keep, m->keepCap, (size_t)nq, s); if (rc) return rc;
     rc = grow(m->d_out, m->outCap, (size_t)nq, s); if (rc) return rc;
     rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
-    SSVIO_HIP(hipMemcpy2DAsync(m->d_q, 32, q, qstride, 32, nq, hipMemcpyHostToDevice, s));
+    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
     SSVIO_HIP(hipMemcpyAsync(m->d_p3d, p3d, (size_t)nq * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     if (nt > 0) {
-        SSVIO_HIP(hipMemcpy2DAsync(m->d_t, 32, t, tstride, 32, nt, hipMemcpyHostToDevice, s));
+        rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
         SSVIO_HIP(hipMemcpyAsync(m->d_p2d, p2d, (size_t)nt * 2 * sizeof(double), hipMemcpyHostToDevice, s));
     }
     ProjectArgs a{};

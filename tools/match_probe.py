@@ -25,4 +25,26 @@ run("cfg2 64 pairs 1000x1000 bf", 64, 1000, [[f, (f - 1) % 64] for f in range(64
 run("cfg3 1 pair 4000x4000 knn2", 2, 4000, [[0, 1]], 1)
 run("cfg4 64 pairs 4000x4000 crosscheck", 65, 4000, [[0, k + 1] for k in range(64)], 2)
 run("cfg5-like 256 pairs 8000x8000 bf", 24, 8000, [[i, j] for i in range(24) for j in range(i)][:256], 0, iters=5)
+# MatchByProject (host buffers in, matches out): kernel time and end-to-end call time
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+from test_gpu_match import _project_scene
+for n1, n2, rad in ((1000, 1000, 15.0), (4000, 4000, 25.0)):
+    P3, dq, p2, dt_, K, R, t = _project_scene(3, n1, n2, synth)
+    for _ in range(3): fm.MatchByProject(P3, dq, p2, dt_, rad, K, R, t)
+    fm.set_profiling(True); t0 = time.perf_counter()
+    for _ in range(20): ok, m = fm.MatchByProject(P3, dq, p2, dt_, rad, K, R, t)
+    wall = (time.perf_counter() - t0) / 20
+    kt = fm.kernel_times(); fm.set_profiling(False)
+    print("MatchByProject %dx%d radian %g: %d matches, kernels %.1f us, call (H2D + kernels + D2H) %.1f us" % (n1, n2, rad, len(m), kt["k_match_project"][0] * 1e3 / kt["k_match_project"][1], wall * 1e6))
+# host-buffer entry points, as the C++ adapters call them (PCIe-inclusive)
+ex = ssvio_amd.ORBextractor(1000, 1.2, 8, 20, 7)
+fr = synth.frame_stream(9, 2, 480, 640)
+for _ in range(3): ka, da = ex.Extract(fr[0]); kb, db = ex.Extract(fr[1]); fm.MatchByBruteForce(db, da)
+t0 = time.perf_counter()
+for _ in range(50): ka, da = ex.Extract(fr[0])
+t1 = time.perf_counter()
+for _ in range(50): fm.MatchByBruteForce(db, da)
+t2 = time.perf_counter()
+print("host path: Extract(VGA, 1000) %.1f us per call, MatchByBruteForce(%dx%d) %.1f us per call" % ((t1 - t0) / 50 * 1e6, len(db), len(da), (t2 - t1) / 50 * 1e6))
+ex.close()
 fm.close()
