@@ -228,7 +228,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    if world > 1 or os.environ.get("SSVIO_BENCH_FORCE_DIST"):     # FORCE_DIST: exercise the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # rehearsal knobs for a one-GPU box: SSVIO_BENCH_BACKEND=gloo SSVIO_BENCH_ONE_DEVICE=1 put every rank on cuda:0
