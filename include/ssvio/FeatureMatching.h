@@ -1,10 +1,16 @@
 // FeatureMatching.h -- drop-in for SSVIO's include/FeatureMatching.h:13-54 on the gfx950 library.
 // The constructor keeps its shape (vocabulary path + config); the config is anything with
-// GetParam<T>(key) like SSVIO's Config (include/Config.h:26-30).  MatchByDBoW needs DBoW3 and its
-// vocabulary (un-vendored, blob missing from the reference tree): it is declared and returns false
-// without touching `matches`' contents beyond what the reference's early return does.
+// GetParam<T>(key) like SSVIO's Config (include/Config.h:26-30).  The vocabulary (DBoW3::Vocabulary in the
+// reference, src/FeatureMatching.cpp:8-9) is read from voc_dataset when that is a text vocabulary
+// (DBoW3 load_fromtxt / ORBvoc.txt layout: "k L scoring weighting", then "parent is_leaf d0..d31 weight" per
+// node) or handed over as arrays with SetVocabulary; DBoW3's compressed binary container is not read.  Without
+// a vocabulary MatchByDBoW returns false (lastStatus() tells why).
 #pragma once
+#include <cmath>
+#include <fstream>
+#include <map>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -22,9 +28,10 @@ public:
         mTh_ = config->template GetParam<int>("Threshold");          // src/FeatureMatching.cpp:10
         mNNRatio_ = config->template GetParam<float>("NNRatio");      // :11
         init(device);
+        LoadVocabularyTxt(voc_.c_str());                              // :8-9 (a missing / unreadable file leaves no vocabulary)
     }
     FeatureMatching(int threshold, float nnRatio, int device = 0) : mTh_(threshold), mNNRatio_(nnRatio) { init(device); }
-    ~FeatureMatching() { ssvio_matcher_destroy(m_); }
+    ~FeatureMatching() { ssvio_matcher_destroy(m_); ssvio_vocab_destroy(v_); }
     FeatureMatching(const FeatureMatching&) = delete;
     FeatureMatching& operator=(const FeatureMatching&) = delete;
 
@@ -36,14 +43,77 @@ public:
     { return run(ssvio_match_knn2_ratio, desp1, desp2, matches); }
     bool MatchByCrossCheck(cv::Mat& desp1, cv::Mat& desp2, std::vector<cv::DMatch>& matches)
     { return run(ssvio_match_crosscheck, desp1, desp2, matches); }
-    // include/FeatureMatching.h:27 -- out of scope (DBoW3); mirrors the early return of :61-63
+    // DBoW3's typedefs: BowVector = map<WordId, WordValue>, FeatureVector = map<NodeId, vector<unsigned>>
+    typedef std::map<unsigned int, double> BowVector;
+    typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;
+
+    // the vocabulary as a node table (include/ssvio_gpu.h, ssvio_vocab_create): node 0 = root, parent[n] < n
+    bool SetVocabulary(int k, int L, const std::vector<int32_t>& parent, const std::vector<uint8_t>& desc,
+                       const std::vector<double>& weight, const std::vector<int32_t>& word, int scoring = 0, int weighting = 0)
+    {
+        ssvio_vocab_destroy(v_); v_ = nullptr;
+        const int n = (int)parent.size();
+        if (desc.size() != (size_t)n * 32 || weight.size() != (size_t)n || word.size() != (size_t)n) { status_ = SSVIO_ERR_INVALID; return false; }
+        status_ = ssvio_vocab_create(device_, k, L, n, parent.data(), desc.data(), weight.data(), word.data(), scoring, weighting, &v_);
+        scoring_ = scoring; weighting_ = weighting;
+        return status_ == SSVIO_OK;
+    }
+    bool LoadVocabularyTxt(const char* path)
+    {
+        std::ifstream f(path);
+        if (!f) return false;
+        int k = 0, L = 0, scoring = 0, weighting = 0;
+        std::string line;
+        if (!std::getline(f, line)) return false;
+        { std::istringstream ls(line); if (!(ls >> k >> L >> scoring >> weighting)) return false; }
+        if (k < 1 || k > 65536 || L < 0 || L > 64 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3) return false;
+        std::vector<int32_t> parent(1, -1), word(1, -1); std::vector<uint8_t> desc(32, 0); std::vector<double> weight(1, 0.0);
+        int nwords = 0;
+        while (std::getline(f, line)) {
+            std::istringstream ls(line);
+            int pid, leaf;
+            if (!(ls >> pid >> leaf)) continue;
+            for (int i = 0; i < 32; ++i) { int b; if (!(ls >> b)) return false; desc.push_back((uint8_t)b); }
+            double w; if (!(ls >> w)) return false;
+            parent.push_back(pid); weight.push_back(w); word.push_back(leaf > 0 ? nwords++ : -1);
+        }
+        return SetVocabulary(k, L, parent, desc, weight, word, scoring, weighting);
+    }
+    bool HasVocabulary() const { return v_ != nullptr; }
+
+    // src/FeatureMatching.cpp:192-208: mVoc_->transform(allDesp, bowVec, featVec, 4)
+    void ComputeBoWVector(cv::Mat& desp, BowVector& bowVec, FeatureVector& featVec)
+    {
+        bowVec.clear(); featVec.clear();                              // :195-196
+        if (!v_ || desp.rows <= 0 || desp.cols != 32) { status_ = v_ ? SSVIO_OK : SSVIO_ERR_INVALID; return; }
+        std::vector<int32_t> word(desp.rows), node(desp.rows); std::vector<double> weight(desp.rows);
+        status_ = ssvio_bow_transform(m_, v_, desp.ptr(0), desp.rows, (int)desp.step, 4, word.data(), node.data(), weight.data());
+        if (status_ == SSVIO_OK) fill_vectors(word, node, weight, bowVec, featVec);
+    }
+
+    // include/FeatureMatching.h:27, src/FeatureMatching.cpp:58-125
     bool MatchByDBoW(cv::Mat& desp1, cv::Mat& desp2, std::vector<cv::DMatch>& matches)
     {
-        if (!(desp1.rows > 0 && desp2.rows > 0)) return false;
-        matches.clear();
-        status_ = SSVIO_ERR_INVALID;
-        return false;
+        if (!(desp1.rows > 0 && desp2.rows > 0)) return false;        // :61-63, before the clear
+        matches.clear();                                              // :65
+        if (!v_ || desp1.cols != 32 || desp2.cols != 32) { status_ = SSVIO_ERR_INVALID; return false; }
+        matches.resize(desp1.rows);
+        int n = 0;
+        status_ = ssvio_match_dbow(m_, v_, desp1.ptr(0), desp1.rows, (int)desp1.step, desp2.ptr(0), desp2.rows, (int)desp2.step, 4,
+                                   (ssvio_dmatch*)matches.data(), desp1.rows, &n);
+        matches.resize(status_ == SSVIO_OK ? n : 0);
+        if (status_ == SSVIO_OK) {                                    // the members :68-69 fill
+            for (int side = 0; side < 2; ++side) {
+                const int rows = side ? desp2.rows : desp1.rows; int got = 0;
+                std::vector<int32_t> word(rows), node(rows); std::vector<double> weight(rows);
+                if (ssvio_bow_last_transform(m_, side, word.data(), node.data(), weight.data(), rows, &got) != SSVIO_OK) break;
+                fill_vectors(word, node, weight, side ? mBowVec2_ : mBowVec1_, side ? mFeatVec2_ : mFeatVec1_);
+            }
+        }
+        return matches.size() > 0;                                    // :124
     }
+    BowVector mBowVec1_, mBowVec2_;                                   // include/FeatureMatching.h:46-49 (private there)
+    FeatureVector mFeatVec1_, mFeatVec2_;
     // include/FeatureMatching.h:30-32, src/FeatureMatching.cpp:128-189; K, R 3x3 and t 3x1 are CV_64F like the reference's
     bool MatchByProject(std::vector<cv::Point3d>& vp3d1, cv::Mat& desp1, std::vector<cv::Point2d>& vp2d2, cv::Mat& desp2,
                         double& radian, cv::Mat& K, cv::Mat& R, cv::Mat& t, std::vector<cv::DMatch>& matches)
@@ -73,8 +143,30 @@ public:
 
 private:
     typedef int (*MatchFn)(ssvio_matcher*, const uint8_t*, int, int, const uint8_t*, int, int, ssvio_dmatch*, int, int*);
+    // the two maps of Vocabulary::transform(features, v, fv, levelsup) from the per-feature results
+    void fill_vectors(const std::vector<int32_t>& word, const std::vector<int32_t>& node, const std::vector<double>& weight,
+                      BowVector& bv, FeatureVector& fv)
+    {
+        bv.clear(); fv.clear();
+        const bool tf = weighting_ == 0 || weighting_ == 1, must = scoring_ != 5;
+        for (size_t i = 0; i < word.size(); ++i) {
+            if (!(weight[i] > 0)) continue;                           // stopped word
+            BowVector::iterator it = bv.lower_bound((unsigned)word[i]);
+            if (it != bv.end() && it->first == (unsigned)word[i]) { if (tf) it->second += weight[i]; }   // addWeight / addIfNotExist
+            else bv.insert(it, BowVector::value_type((unsigned)word[i], weight[i]));
+            fv[(unsigned)node[i]].push_back((unsigned)i);
+        }
+        if (tf && !bv.empty() && !must) { const double nd = (double)bv.size(); for (auto& e : bv) e.second /= nd; }
+        if (must) {
+            double norm = 0.0;
+            if (scoring_ == 1) { for (auto& e : bv) norm += e.second * e.second; norm = std::sqrt(norm); }
+            else for (auto& e : bv) norm += std::fabs(e.second);
+            if (norm > 0.0) for (auto& e : bv) e.second /= norm;
+        }
+    }
     void init(int device)
     {
+        device_ = device;
         if (ssvio_matcher_create(mTh_, mNNRatio_, device, &m_) != SSVIO_OK) throw std::runtime_error(std::string("FeatureMatching: ") + ssvio_last_error());
     }
     bool run(MatchFn fn, cv::Mat& d1, cv::Mat& d2, std::vector<cv::DMatch>& matches)
@@ -93,5 +185,7 @@ private:
     std::string voc_;
     int mTh_; float mNNRatio_;
     ssvio_matcher* m_ = nullptr;
+    ssvio_vocab* v_ = nullptr;
+    int device_ = 0, scoring_ = 0, weighting_ = 0;
     int status_ = SSVIO_OK;
 };

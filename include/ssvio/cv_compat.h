@@ -1,7 +1,7 @@
 // cv_compat.h -- the few cv:: types the adapters touch.
 // With -DSSVIO_HAVE_OPENCV the real OpenCV headers are used and SSVIO's other sources compile
 // unchanged against the adapters.  Without OpenCV (this build image has none) a minimal set of
-// layout-compatible PODs (KeyPoint 28 B, DMatch 16 B, Point2d/3d, a ref-counted 8-bit / 64F Mat) keeps the adapters
+// layout-compatible PODs (KeyPoint 28 B, DMatch 16 B, Point2d/3d, a ref-counted 8-bit / 16U / 64F Mat) keeps the adapters
 // compilable and testable.  This is NOT an OpenCV replacement and is not used to build the reference.
 #pragma once
 #ifdef SSVIO_HAVE_OPENCV
@@ -19,6 +19,8 @@ enum { CV_8UC1_ = 0, CV_8UC3_ = 16 };
 #define CV_8UC1 0
 #define CV_8UC3 16
 #define CV_64F 6
+#define CV_16U 2
+#define CV_16UC1 2
 #endif
 struct Point2f { float x, y; Point2f(float x_ = 0, float y_ = 0) : x(x_), y(y_) {} };
 struct Point2d { double x, y; Point2d(double x_ = 0, double y_ = 0) : x(x_), y(y_) {} };
@@ -48,7 +50,7 @@ public:
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     int type() const { return type_; }
     int channels() const { return type_ == CV_8UC3 ? 3 : 1; }
-    size_t elemSize() const { return type_ == CV_64F ? 8 : (size_t)channels(); }
+    size_t elemSize() const { return type_ == CV_64F ? 8 : type_ == CV_16U ? 2 : (size_t)channels(); }
     bool isContinuous() const { return step == (size_t)cols * elemSize(); }
     template <class T> T& at(int r, int c = 0) { return *(T*)(data + (size_t)r * step + (size_t)c * sizeof(T)); }
     unsigned char* ptr(int r = 0) { return data + (size_t)r * step; }

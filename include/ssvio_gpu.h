@@ -145,7 +145,7 @@ int  ssvio_orb_set_stream(ssvio_orb* h, void* hip_stream);
 
 /* ---- matcher: replaces class FeatureMatching (include/FeatureMatching.h:13-54) ---- */
 /* FeatureMatching::FeatureMatching reads Threshold / NNRatio (src/FeatureMatching.cpp:10-11).
- * The DBoW3 vocabulary it also loads belongs to MatchByDBoW, which is out of scope. */
+ * The DBoW3 vocabulary it also loads (:8-9) is a separate object here: ssvio_vocab_create below. */
 int  ssvio_matcher_create(int threshold, float nn_ratio, int device, ssvio_matcher** out);
 void ssvio_matcher_destroy(ssvio_matcher* m);
 int  ssvio_matcher_set_stream(ssvio_matcher* m, void* hip_stream);
@@ -196,6 +196,84 @@ int  ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_
 int  ssvio_matcher_sync(ssvio_matcher* m);
 /* copy batched results to the host: out[npairs][max_rows], n[npairs] */
 int  ssvio_match_batch_fetch(ssvio_matcher* m, int npairs, int max_rows, ssvio_dmatch* out, int32_t* n);
+
+
+/* ---- MatchByDBoW ------------------------------------------------------------------------
+ * FeatureMatching::FeatureMatching loads a DBoW3::Vocabulary (src/FeatureMatching.cpp:8-9); DBoW3 is an un-vendored
+ * third-party library and the vocabulary blob is missing from the reference tree (.MISSING_LARGE_BLOBS), so the
+ * vocabulary crosses this boundary as a plain node table: node 0 is the root, parent[n] < n, the children of a node
+ * are its nodes in ascending id (the order DBoW3 creates, saves and loads them in), desc[nnodes][32] (row 0 unused),
+ * weight[nnodes], word[nnodes] = word id of a leaf (ignored for inner nodes).  k, L: branching factor and depth
+ * (DBoW3's m_k, m_L).  scoring: DBoW3's ScoringType 0..5 (L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT);
+ * weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (DBoW3's enums; they only shape the BowVector the host assembles, not the matching). */
+typedef struct ssvio_vocab ssvio_vocab;
+int  ssvio_vocab_create(int device, int k, int L, int nnodes, const int32_t* parent, const uint8_t* desc, const double* weight,
+                        const int32_t* word, int scoring, int weighting, ssvio_vocab** out);
+void ssvio_vocab_destroy(ssvio_vocab* v);
+int  ssvio_vocab_info(const ssvio_vocab* v, int* k, int* L, int* nnodes, int* scoring, int* weighting);
+/* FeatureMatching::ComputeBoWVector (src/FeatureMatching.cpp:192-208) = DBoW3 Vocabulary::transform(features, bowVec,
+ * featVec, levelsup = 4), per feature: word[i], weight[i] of the leaf reached and node[i], the node passed at level
+ * L - levelsup (0 when that level is <= 0 or is never reached).  The BowVector (word -> summed weight, normalised) and
+ * the FeatureVector (node -> ascending feature indices) follow from these on the host; features with weight <= 0 enter
+ * neither. */
+int  ssvio_bow_transform(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* desc, int n, int stride, int levelsup,
+                         int32_t* word, int32_t* node, double* weight);
+/* FeatureMatching::MatchByDBoW(desp1, desp2, matches), include/FeatureMatching.h:27, src/FeatureMatching.cpp:58-125: both
+ * sets are transformed (levelsup = 4 in the reference, :206); for every vocabulary node present in both feature vectors,
+ * in ascending node id, every query feature of the node (ascending index) takes its best / second-best Hamming distance
+ * over the node's train features and is kept iff best <= Threshold and best < NNRatio * second (:104-105).
+ * out[cap >= nq]: DMatch{queryIdx, trainIdx, imgIdx = -1, distance} in that order.  *n = 0 when either set is empty
+ * (:61-63; the reference then leaves `matches` untouched -- the adapter's business). */
+int  ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, int nq, int qstride,
+                      const uint8_t* t, int nt, int tstride, int levelsup, ssvio_dmatch* out, int cap, int* n);
+/* per-feature transform results of the last ssvio_match_dbow / ssvio_bow_transform call (mBowVec1_/mFeatVec1_ for side 0,
+ * mBowVec2_/mFeatVec2_ for side 1, include/FeatureMatching.h:46-49); *n = rows of that side */
+int  ssvio_bow_last_transform(ssvio_matcher* m, int side, int32_t* word, int32_t* node, double* weight, int cap, int* n);
+/* batched, device-resident form (same layout as ssvio_match_batch_dev; nsets descriptor sets, each transformed once) */
+int  ssvio_match_dbow_batch_dev(ssvio_matcher* m, const ssvio_vocab* v, const void* d_desc, int set_stride_rows, int max_rows,
+                                const int32_t* d_counts, int nsets, const int32_t* pairs, int npairs, int levelsup,
+                                const void** d_matches, const int32_t** d_nmatches);
+
+/* ---- behind the matcher --------------------------------------------------------------- */
+/* Frame's static camera parameters, include/Frame.h:46-52, include/Init.h:14-20.  depth_scale is the already divided
+ * value (yaml DepthScale / 65535.0 narrowed to float, Init.h:18); 1/fx and 1/fy are formed in float like Init.h:19-20. */
+typedef struct ssvio_camera { float cx, cy, fx, fy, depth_scale; } ssvio_camera;
+/* Frame::Get3DPoint(index), src/Frame.cpp:93-108, for keypoints 0..n-1: out[n][3] floats.  depth: 16U image, w x h,
+ * stride_px pixels per row; the pixel is (int)pt.y, (int)pt.x like Mat::at<ushort>(float, float). */
+int  ssvio_get_3d_points(ssvio_matcher* m, const ssvio_keypoint* kps, int n, const uint16_t* depth, int w, int h, int stride_px,
+                         const ssvio_camera* cam, float* out);
+/* The two filter loops of Odometry::OptimizeTransform, src/Odometry.cpp:44-64 and :94-108, over matches[nm]
+ * (trainIdx -> last frame, queryIdx -> current frame).  First lists (matches whose last-frame point has
+ * z >= depth_scale, in match order): last3d[.][3], cur2d[.][2], cur3d[.][3], pre_good[.] -- the solvePnPRansac inputs.
+ * Second lists (of those, the ones whose current-frame point has z >= depth_scale): edge_last3d, edge_cur3d (the
+ * AddCVMeasure pairs) and final_good (_final_good_match).  Every output array holds nm entries. */
+int  ssvio_assemble_correspondences(ssvio_matcher* m, const ssvio_dmatch* matches, int nm,
+                                    const ssvio_keypoint* last_kps, int nlast, const uint16_t* last_depth,
+                                    const ssvio_keypoint* cur_kps, int ncur, const uint16_t* cur_depth,
+                                    int w, int h, int stride_px, const ssvio_camera* cam,
+                                    float* last3d, float* cur2d, float* cur3d, ssvio_dmatch* pre_good, int* n_pre,
+                                    float* edge_last3d, float* edge_cur3d, ssvio_dmatch* final_good, int* n_final);
+/* device-resident, batched: chains behind ssvio_match_*_batch_dev and ssvio_orb_extract_batch_dev without a host
+ * round trip.  pairs[npairs][2] = (current set, last set) as given to the matcher; d_kps / d_kpcounts as returned by
+ * ssvio_orb_device_results (kp_stride entries per set); d_depth: one w x h 16U image per set, depth_frame_stride pixels
+ * apart.  Outputs stay in HBM inside the handle, [pair][max_rows] each; d_counts[pair][2] = {n_pre, n_final}. */
+typedef struct ssvio_correspondences_dev {
+    const float* last3d; const float* cur2d; const float* cur3d; const ssvio_dmatch* pre_good;
+    const float* edge_last3d; const float* edge_cur3d; const ssvio_dmatch* final_good;
+    const int32_t* counts;
+} ssvio_correspondences_dev;
+int  ssvio_assemble_batch_dev(ssvio_matcher* m, const void* d_matches, const int32_t* d_nmatches, int max_rows,
+                              const int32_t* pairs, int npairs, const void* d_kps, int kp_stride, const int32_t* d_kpcounts,
+                              const void* d_depth, size_t depth_frame_stride, int w, int h, int stride_px,
+                              const ssvio_camera* cam, ssvio_correspondences_dev* out);
+/* Map::TrackMapPoints(last_match_vec, this_match_vec), src/Map.cpp:100-123: for every last match, in order, the first
+ * this-match whose trainIdx equals its queryIdx gives DMatch{queryIdx = this.queryIdx, trainIdx = last.trainIdx,
+ * imgIdx = -1, distance = FLT_MAX (cv::DMatch() defaults)}.  out[cap >= nlast].  The O(N^2) search is an index map here. */
+int  ssvio_track_map_points(ssvio_matcher* m, const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, int ncur,
+                            ssvio_dmatch* out, int cap, int* n);
+/* Map::InMatchVec(i, vec), src/Map.cpp:151-162, for i = 0..nkp-1 (the loop of ManageMapPoints, :128-131):
+ * out[i] = index of the first match with queryIdx == i, or -1 */
+int  ssvio_in_match_vec(ssvio_matcher* m, const ssvio_dmatch* vec, int n, int nkp, int32_t* out);
 
 #ifdef __cplusplus
 }

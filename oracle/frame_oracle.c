@@ -1,0 +1,86 @@
+/* frame_oracle.c -- CPU restatement of the steps right behind the matcher (TEST INFRASTRUCTURE ONLY).
+ *
+ * PARITY UNPINNED (see ssvio_oracle.h).  Follows /root/reference:
+ *   src/Frame.cpp:93-108        Frame::Get3DPoint                      -> orc_get_3d_point
+ *   src/Odometry.cpp:44-64      correspondence assembly (PnP inputs)   -> orc_assemble_correspondences, first list
+ *   src/Odometry.cpp:94-108     ICP edge list / _final_good_match      -> orc_assemble_correspondences, second list
+ *   src/Map.cpp:100-123         Map::TrackMapPoints                    -> orc_track_map_points
+ *   src/Map.cpp:151-162         Map::InMatchVec (for every keypoint)   -> orc_in_match_vec
+ *   All float arithmetic is single precision, evaluated left to right, no contraction.
+ */
+#include "ssvio_oracle.h"
+#include <float.h>
+#include <stddef.h>
+
+/* cam: InnerCx, InnerCy, InnerFx, InnerFy, DepthScale (= yaml DepthScale / 65535.0 narrowed to float, include/Init.h:14-20) */
+void orc_get_3d_point(const orc_keypoint* kps, int index, const uint16_t* depth, int depth_stride_px,
+                      const float cam[5], float out[3])
+{
+    const float inv_fx = 1 / cam[2], inv_fy = 1 / cam[3];           /* include/Init.h:19-20 */
+    const float pos_x = kps[index].x, pos_y = kps[index].y;         /* :98-99 */
+    /* :101 Mat::at<ushort>(int, int) called with floats: both truncate toward zero */
+    const float d = (float)depth[(size_t)(int)pos_y * depth_stride_px + (int)pos_x] * cam[4];
+    out[0] = (pos_x - cam[0]) * d * inv_fx;                         /* :103 */
+    out[1] = (pos_y - cam[1]) * d * inv_fy;                         /* :104 */
+    out[2] = d;                                                     /* :105 */
+}
+
+/* src/Odometry.cpp:44-64 then :94-108.  match.trainIdx indexes the last frame, match.queryIdx the current one.
+ * pre lists (one entry per match whose last-frame point has z >= DepthScale): last3d, cur2d, cur3d, pre_good;
+ * final lists (those whose current-frame point has z >= DepthScale too): edge_last3d, edge_cur3d, final_good. */
+void orc_assemble_correspondences(const orc_dmatch* matches, int nm,
+                                  const orc_keypoint* last_kps, const uint16_t* last_depth,
+                                  const orc_keypoint* cur_kps, const uint16_t* cur_depth, int depth_stride_px,
+                                  const float cam[5],
+                                  float* last3d, float* cur2d, float* cur3d, orc_dmatch* pre_good, int* n_pre,
+                                  float* edge_last3d, float* edge_cur3d, orc_dmatch* final_good, int* n_final)
+{
+    int np = 0, nf = 0;
+    for (int i = 0; i < nm; ++i) {
+        float lp[3];
+        orc_get_3d_point(last_kps, matches[i].trainIdx, last_depth, depth_stride_px, cam, lp);   /* :50 */
+        if (lp[2] >= cam[4]) {                                                                   /* :51 */
+            last3d[3 * np] = lp[0]; last3d[3 * np + 1] = lp[1]; last3d[3 * np + 2] = lp[2];
+            cur2d[2 * np] = cur_kps[matches[i].queryIdx].x; cur2d[2 * np + 1] = cur_kps[matches[i].queryIdx].y;   /* :54-56 */
+            orc_get_3d_point(cur_kps, matches[i].queryIdx, cur_depth, depth_stride_px, cam, cur3d + 3 * np);     /* :59 */
+            pre_good[np] = matches[i];
+            ++np;
+        }
+    }
+    for (int i = 0; i < np; ++i) {                                                               /* :94-108 */
+        if (cur3d[3 * i + 2] >= cam[4]) {
+            for (int c = 0; c < 3; ++c) { edge_last3d[3 * nf + c] = last3d[3 * i + c]; edge_cur3d[3 * nf + c] = cur3d[3 * i + c]; }
+            final_good[nf] = pre_good[i];
+            ++nf;
+        }
+    }
+    *n_pre = np; *n_final = nf;
+}
+
+/* Map::TrackMapPoints, src/Map.cpp:100-123: for every last match, in order, the FIRST this-match whose trainIdx equals
+ * its queryIdx; emits DMatch{queryIdx = this.queryIdx, trainIdx = last.trainIdx} with cv::DMatch()'s defaults in the
+ * other two fields (imgIdx -1, distance FLT_MAX). */
+int orc_track_map_points(const orc_dmatch* last, int nlast, const orc_dmatch* cur, int ncur, orc_dmatch* out)
+{
+    int n = 0;
+    for (int i = 0; i < nlast; ++i) {
+        for (int j = 0; j < ncur; ++j) {
+            if (last[i].queryIdx == cur[j].trainIdx) {
+                orc_dmatch m; m.queryIdx = cur[j].queryIdx; m.trainIdx = last[i].trainIdx; m.imgIdx = -1; m.distance = FLT_MAX;
+                out[n++] = m;
+                break;
+            }
+        }
+    }
+    return n;
+}
+
+/* Map::InMatchVec(i, vec), src/Map.cpp:151-162, for i = 0..nkp-1 (the loop of ManageMapPoints, :128-131):
+ * index of the first match whose queryIdx is i, or -1 */
+void orc_in_match_vec(const orc_dmatch* vec, int n, int nkp, int32_t* out)
+{
+    for (int i = 0; i < nkp; ++i) {
+        out[i] = -1;
+        for (int j = 0; j < n; ++j) if (vec[j].queryIdx == i) { out[i] = j; break; }
+    }
+}

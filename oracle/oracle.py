@@ -19,7 +19,8 @@ assert KP_DTYPE.itemsize == 28 and DM_DTYPE.itemsize == 16
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "ssvio_oracle.h", "orb_pattern.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.c", "match_oracle.c", "bow_oracle.c", "frame_oracle.c",
+                                                 "ssvio_oracle.h", "orb_pattern.inc")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
@@ -74,6 +75,15 @@ def lib():
         L.orc_match_bruteforce.restype = i32; L.orc_match_bruteforce.argtypes = [vp, i32, i32, vp, i32, i32, vp]
         L.orc_match_knn2_ratio.restype = i32; L.orc_match_knn2_ratio.argtypes = [vp, i32, i32, vp, i32, i32, i32, f32, vp]
         L.orc_match_crosscheck.restype = i32; L.orc_match_crosscheck.argtypes = [vp, i32, i32, vp, i32, i32, vp]
+        L.orc_vocab_create.restype = vp; L.orc_vocab_create.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, i32]
+        L.orc_vocab_destroy.argtypes = [vp]
+        L.orc_bow_transform.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+        L.orc_bow_vector.restype = i32; L.orc_bow_vector.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+        L.orc_match_dbow.restype = i32; L.orc_match_dbow.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, i32, f32, vp]
+        L.orc_get_3d_point.argtypes = [vp, i32, vp, i32, vp, vp]
+        L.orc_assemble_correspondences.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp] + [vp] * 9
+        L.orc_track_map_points.restype = i32; L.orc_track_map_points.argtypes = [vp, i32, vp, i32, vp]
+        L.orc_in_match_vec.argtypes = [vp, i32, i32, vp]
         _lib = L
     return _lib
 
@@ -318,3 +328,92 @@ def match_crosscheck(q, t):
     out = np.zeros(max(len(q), 1), DM_DTYPE)
     n = lib().orc_match_crosscheck(_p(q), len(q), 32, _p(t), len(t), 32, _p(out))
     return out[:n].copy()
+
+
+# ---------------------------------------------------------------- MatchByDBoW (src/FeatureMatching.cpp:58-125, :192-208)
+class Vocabulary:
+    """DBoW3::Vocabulary as a node table (bow_oracle.c): parent[nnodes], desc[nnodes][32], weight[nnodes], word[nnodes]"""
+
+    def __init__(self, k, L, parent, desc, weight, word, scoring=0, weighting=0):
+        self.k, self.L, self.scoring, self.weighting = k, L, scoring, weighting
+        self.parent = np.ascontiguousarray(parent, np.int32); self.desc = _desc(desc)
+        self.weight = np.ascontiguousarray(weight, np.float64); self.word = np.ascontiguousarray(word, np.int32)
+        n = len(self.parent)
+        assert len(self.desc) == n and len(self.weight) == n and len(self.word) == n
+        self._h = lib().orc_vocab_create(k, L, n, _p(self.parent), _p(self.desc), _p(self.weight), _p(self.word), scoring, weighting)
+        if not self._h:
+            raise ValueError("bad vocabulary")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_vocab_destroy(self._h); self._h = None
+
+    def transform(self, desc, levelsup=4):
+        """per feature: (word id, node id at level L - levelsup, weight)"""
+        desc = _desc(desc); n = len(desc)
+        word = np.zeros(n, np.int32); node = np.zeros(n, np.int32); weight = np.zeros(n, np.float64)
+        lib().orc_bow_transform(self._h, _p(desc), n, 32, levelsup, _p(word), _p(node), _p(weight))
+        return word, node, weight
+
+    def bow_vector(self, word, weight):
+        word = np.ascontiguousarray(word, np.int32); weight = np.ascontiguousarray(weight, np.float64)
+        ow = np.zeros(max(len(word), 1), np.int32); ov = np.zeros(max(len(word), 1), np.float64)
+        m = lib().orc_bow_vector(_p(word), _p(weight), len(word), self.scoring, self.weighting, _p(ow), _p(ov))
+        return ow[:m].copy(), ov[:m].copy()
+
+
+def match_dbow(voc, q, t, threshold=50, nn_ratio=0.6, levelsup=4):
+    q = _desc(q); t = _desc(t)
+    if not (len(q) > 0 and len(t) > 0):
+        return np.zeros(0, DM_DTYPE)
+    _, qn, qw = voc.transform(q, levelsup); _, tn, tw = voc.transform(t, levelsup)
+    out = np.zeros(max(len(q), 1), DM_DTYPE)
+    n = lib().orc_match_dbow(_p(q), len(q), 32, _p(qn), _p(qw), _p(t), len(t), 32, _p(tn), _p(tw), threshold, nn_ratio, _p(out))
+    return out[:n].copy()
+
+
+# ---------------------------------------------------------------- behind the matcher (SURVEY §8 f2, f3)
+def camera(cx, cy, fx, fy, depth_scale_yaml):
+    """{InnerCx, InnerCy, InnerFx, InnerFy, DepthScale/65535.0 narrowed to float} (include/Init.h:14-20)"""
+    return np.array([cx, cy, fx, fy, np.float32(np.float64(np.float32(depth_scale_yaml)) / 65535.0)], np.float32)
+
+
+def get_3d_points(kps, depth, cam):
+    kps = np.ascontiguousarray(kps, KP_DTYPE); depth = np.ascontiguousarray(depth, np.uint16)
+    cam = np.ascontiguousarray(cam, np.float32)
+    out = np.zeros((len(kps), 3), np.float32)
+    for i in range(len(kps)):
+        lib().orc_get_3d_point(_p(kps), i, _p(depth), depth.shape[1], _p(cam), C.c_void_p(out.ctypes.data + 12 * i))
+    return out
+
+
+def assemble_correspondences(matches, last_kps, last_depth, cur_kps, cur_depth, cam):
+    m = np.ascontiguousarray(matches, DM_DTYPE); nm = len(m)
+    lk = np.ascontiguousarray(last_kps, KP_DTYPE); ck = np.ascontiguousarray(cur_kps, KP_DTYPE)
+    ld = np.ascontiguousarray(last_depth, np.uint16); cd = np.ascontiguousarray(cur_depth, np.uint16)
+    assert ld.shape == cd.shape
+    cam = np.ascontiguousarray(cam, np.float32)
+    cap = max(nm, 1)
+    last3d = np.zeros((cap, 3), np.float32); cur2d = np.zeros((cap, 2), np.float32); cur3d = np.zeros((cap, 3), np.float32)
+    pre = np.zeros(cap, DM_DTYPE); el = np.zeros((cap, 3), np.float32); ec = np.zeros((cap, 3), np.float32); fin = np.zeros(cap, DM_DTYPE)
+    np_ = C.c_int(0); nf = C.c_int(0)
+    lib().orc_assemble_correspondences(_p(m), nm, _p(lk), _p(ld), _p(ck), _p(cd), ld.shape[1], _p(cam),
+                                       _p(last3d), _p(cur2d), _p(cur3d), _p(pre), C.byref(np_),
+                                       _p(el), _p(ec), _p(fin), C.byref(nf))
+    a, b = np_.value, nf.value
+    return {"last3d": last3d[:a].copy(), "cur2d": cur2d[:a].copy(), "cur3d": cur3d[:a].copy(), "pre_good": pre[:a].copy(),
+            "edge_last3d": el[:b].copy(), "edge_cur3d": ec[:b].copy(), "final_good": fin[:b].copy()}
+
+
+def track_map_points(last, cur):
+    last = np.ascontiguousarray(last, DM_DTYPE); cur = np.ascontiguousarray(cur, DM_DTYPE)
+    out = np.zeros(max(len(last), 1), DM_DTYPE)
+    n = lib().orc_track_map_points(_p(last), len(last), _p(cur), len(cur), _p(out))
+    return out[:n].copy()
+
+
+def in_match_vec(vec, nkp):
+    vec = np.ascontiguousarray(vec, DM_DTYPE)
+    out = np.zeros(nkp, np.int32)
+    lib().orc_in_match_vec(_p(vec), len(vec), nkp, _p(out))
+    return out

@@ -91,6 +91,34 @@ int  orc_match_project(const double* p3d, const uint8_t* q, int n1, int qstride,
                        const double* p2d, const uint8_t* t, int n2, int tstride,
                        double radian, const double* K, const double* R, const double* tr,
                        int threshold, float nn_ratio, orc_dmatch* out);
+
+/* ---- MatchByDBoW (src/FeatureMatching.cpp:58-125, :192-208; DBoW3's transform restated, bow_oracle.c) ---- */
+typedef struct orc_vocab orc_vocab;
+/* node table: node 0 = root, parent[n] < n, children in ascending id, desc[nnodes][32], word[n] >= 0 marks a leaf.
+ * scoring: DBoW3's ScoringType 0..5 (L1 L2 CHI_SQUARE KL BHATTACHARYYA DOT_PRODUCT); weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (DBoW3's enums) */
+orc_vocab* orc_vocab_create(int k, int L, int nnodes, const int32_t* parent, const uint8_t* desc,
+                            const double* weight, const int32_t* word, int scoring, int weighting);
+void orc_vocab_destroy(orc_vocab*);
+void orc_bow_transform(const orc_vocab* v, const uint8_t* desc, int n, int stride, int levelsup,
+                       int32_t* word, int32_t* node, double* weight);
+int  orc_bow_vector(const int32_t* word, const double* weight, int n, int scoring, int weighting,
+                    int32_t* out_word, double* out_value);
+int  orc_match_dbow(const uint8_t* q, int nq, int qstride, const int32_t* qnode, const double* qweight,
+                    const uint8_t* t, int nt, int tstride, const int32_t* tnode, const double* tweight,
+                    int threshold, float nn_ratio, orc_dmatch* out);
+
+/* ---- behind the matcher (frame_oracle.c) ---- */
+/* cam = {InnerCx, InnerCy, InnerFx, InnerFy, DepthScale/65535} (include/Init.h:14-20) */
+void orc_get_3d_point(const orc_keypoint* kps, int index, const uint16_t* depth, int depth_stride_px,
+                      const float cam[5], float out[3]);                                  /* src/Frame.cpp:93-108 */
+void orc_assemble_correspondences(const orc_dmatch* matches, int nm,
+                                  const orc_keypoint* last_kps, const uint16_t* last_depth,
+                                  const orc_keypoint* cur_kps, const uint16_t* cur_depth, int depth_stride_px,
+                                  const float cam[5],
+                                  float* last3d, float* cur2d, float* cur3d, orc_dmatch* pre_good, int* n_pre,
+                                  float* edge_last3d, float* edge_cur3d, orc_dmatch* final_good, int* n_final); /* src/Odometry.cpp:44-64,94-108 */
+int  orc_track_map_points(const orc_dmatch* last, int nlast, const orc_dmatch* cur, int ncur, orc_dmatch* out); /* src/Map.cpp:100-123 */
+void orc_in_match_vec(const orc_dmatch* vec, int n, int nkp, int32_t* out);              /* src/Map.cpp:151-162 */
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,7 @@ SSVIO's ORBextractor / FeatureMatching interfaces.  See DESIGN.md."""
 from ._lib import KP_DTYPE, DM_DTYPE, SsvioError, device_count, MODE_BRUTEFORCE, MODE_KNN2_RATIO, MODE_CROSSCHECK
 from .extractor import ORBextractor, distribute_octtree
 from .matching import FeatureMatching
+from .vocabulary import Vocabulary
 
-__all__ = ["ORBextractor", "FeatureMatching", "distribute_octtree", "KP_DTYPE", "DM_DTYPE", "SsvioError",
+__all__ = ["ORBextractor", "FeatureMatching", "Vocabulary", "distribute_octtree", "KP_DTYPE", "DM_DTYPE", "SsvioError",
            "device_count", "MODE_BRUTEFORCE", "MODE_KNN2_RATIO", "MODE_CROSSCHECK"]

@@ -24,6 +24,11 @@ class OrbParams(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+class CorrespondencesDev(C.Structure):
+    """ssvio_correspondences_dev: device pointers of ssvio_assemble_batch_dev's outputs"""
+    _fields_ = [(n, C.c_void_p) for n in ("last3d", "cur2d", "cur3d", "pre_good", "edge_last3d", "edge_cur3d", "final_good", "counts")]
+
+
 class SsvioError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("ssvio error %d: %s" % (code, msg))
@@ -73,6 +78,18 @@ SYMBOLS = {
     "ssvio_match_batch_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "ssvio_matcher_sync": (_i, [_vp]),
     "ssvio_match_batch_fetch": (_i, [_vp, _i, _i, _vp, _vp]),
+    "ssvio_vocab_create": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "ssvio_vocab_destroy": (None, [_vp]),
+    "ssvio_vocab_info": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "ssvio_bow_transform": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ssvio_match_dbow": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "ssvio_bow_last_transform": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "ssvio_match_dbow_batch_dev": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "ssvio_get_3d_points": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "ssvio_assemble_correspondences": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp] + [_vp] * 9),
+    "ssvio_assemble_batch_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _vp, _vp]),
+    "ssvio_track_map_points": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "ssvio_in_match_vec": (_i, [_vp, _vp, _i, _i, _vp]),
 }
 
 _lib = None
@@ -85,6 +102,13 @@ def lib():
             raise ImportError("libssvio_gpu.so is not built (%s). Build it with "
                               "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C ssvio_amd/csrc`. "
                               "There is no CPU fallback." % LIB_PATH)
+        # Load order matters when PyTorch shares the process: its wheel bundles its own HIP + ROCr runtimes, and a process in
+        # which the system ROCr (pulled in by libssvio_gpu.so) was loaded first leaves torch with "No HIP GPUs are available"
+        # (measured: tools/probe/torch_after_lib.py).  With torch's libraries loaded first both runtimes work.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

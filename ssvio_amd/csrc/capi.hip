@@ -764,6 +764,15 @@ struct ssvio_matcher {
     int* d_pairs = nullptr; size_t pairsCap = 0;
     double* d_p3d = nullptr; size_t p3dCap = 0; double* d_p2d = nullptr; size_t p2dCap = 0;     // MatchByProject inputs
     ssvio_dmatch* d_cand = nullptr; size_t candCap = 0; int* d_keep = nullptr; size_t keepCap = 0;
+    // MatchByDBoW: per-feature transform results (query rows first, then train rows) and the grouped-match scratch
+    int32_t* d_bowWord = nullptr; size_t bowWordCap = 0; int32_t* d_bowNode = nullptr; size_t bowNodeCap = 0;
+    double* d_bowWeight = nullptr; size_t bowWeightCap = 0; int32_t* d_gnode = nullptr; size_t gnodeCap = 0;
+    int32_t* d_keepNode = nullptr; size_t keepNodeCap = 0;
+    int lastBowQ = 0, lastBowT = 0;
+    // behind the matcher (f2, f3)
+    uint8_t* d_frameIn = nullptr; size_t frameInCap = 0;      // uploaded matches / keypoints / depth of the host entry points
+    uint8_t* d_frameOut = nullptr; size_t frameOutCap = 0;    // assembled lists
+    uint32_t* d_table = nullptr; size_t tableCap = 0;
     std::vector<uint8_t> stageQ, stageT;              // packed copies of strided descriptor rows
     std::vector<int32_t> h_pairs;                     // what d_pairs holds (an unchanged pair list is not uploaded again)
     KernelProfiler prof; std::string profOnly;
@@ -806,6 +815,18 @@ static void pick_chunks(int maxQ, int maxT, int npairs, int& nChunks, int& chunk
     nChunks = (int)std::max<long>(want, 1);
     chunkRows = ((maxT + nChunks - 1) / nChunks + 127) / 128 * 128;
     nChunks = std::max(1, (maxT + chunkRows - 1) / chunkRows);
+}
+
+// the pair list of the batched entry points, on the device (an unchanged list is not uploaded again)
+static int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs)
+{
+    if (m->h_pairs.size() == (size_t)npairs * 2 && memcmp(m->h_pairs.data(), pairs, (size_t)npairs * 2 * sizeof(int32_t)) == 0) return SSVIO_OK;
+    int rc = grow(m->d_pairs, m->pairsCap, (size_t)npairs * 2, m->stream); if (rc) return rc;
+    SSVIO_HIP(hipStreamSynchronize(m->stream));    // earlier launches may still read the old list
+    m->h_pairs.assign(pairs, pairs + (size_t)npairs * 2);
+    SSVIO_HIP(hipMemcpyAsync(m->d_pairs, m->h_pairs.data(), (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    return SSVIO_OK;
 }
 
 // shared driver: descriptors on the device; pairs == nullptr means the single pair (0,0)
@@ -927,6 +948,8 @@ void ssvio_matcher_destroy(ssvio_matcher* m)
     dfree(m->d_q); dfree(m->d_t); dfree(m->d_counts2); dfree(m->d_partial); dfree(m->d_partialRev);
     dfree(m->d_out); dfree(m->d_raw); dfree(m->d_nout); dfree(m->d_pairs);
     dfree(m->d_p3d); dfree(m->d_p2d); dfree(m->d_cand); dfree(m->d_keep);
+    dfree(m->d_bowWord); dfree(m->d_bowNode); dfree(m->d_bowWeight); dfree(m->d_gnode); dfree(m->d_keepNode);
+    dfree(m->d_frameIn); dfree(m->d_frameOut); dfree(m->d_table);
     if (m->own) (void)hipStreamDestroy(m->own);
     delete m;
 }
@@ -1040,15 +1063,7 @@ int ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_r
     if (max_rows > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
     SSVIO_HIP(hipSetDevice(m->device));
     int rc = SSVIO_OK;
-    if (m->h_pairs.size() != (size_t)npairs * 2 || memcmp(m->h_pairs.data(), pairs, (size_t)npairs * 2 * sizeof(int32_t)) != 0) {
-        const size_t capBefore = m->pairsCap;
-        rc = grow(m->d_pairs, m->pairsCap, (size_t)npairs * 2, m->stream); if (rc) return rc;
-        (void)capBefore;
-        SSVIO_HIP(hipStreamSynchronize(m->stream));    // earlier launches may still read the old list
-        m->h_pairs.assign(pairs, pairs + (size_t)npairs * 2);
-        SSVIO_HIP(hipMemcpyAsync(m->d_pairs, m->h_pairs.data(), (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
-        SSVIO_HIP(hipStreamSynchronize(m->stream));
-    }
+    rc = upload_pairs(m, pairs, npairs); if (rc) return rc;
     rc = match_run(m, (const uint8_t*)d_desc, set_stride_rows, d_counts, (const uint8_t*)d_desc, set_stride_rows, d_counts,
                    m->d_pairs, npairs, max_rows, max_rows, mode);
     if (rc) return rc;
@@ -1074,6 +1089,443 @@ int ssvio_match_batch_fetch(ssvio_matcher* m, int npairs, int max_rows, ssvio_dm
     SSVIO_HIP(hipMemcpyAsync(n, m->d_nout, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     if (out) SSVIO_HIP(hipMemcpyAsync(out, m->d_out, (size_t)npairs * max_rows * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost, m->stream));
     SSVIO_HIP(hipStreamSynchronize(m->stream));
+    return SSVIO_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================
+// MatchByDBoW (src/FeatureMatching.cpp:58-125, :192-208)
+struct ssvio_vocab {
+    int device = 0, k = 0, L = 0, nnodes = 0, scoring = 0, weighting = 0;
+    uint4* d_cdesc = nullptr; int* d_childBegin = nullptr; int* d_child = nullptr; int* d_word = nullptr; double* d_weight = nullptr;
+};
+
+static VocabDev vocab_dev(const ssvio_vocab* v)
+{
+    VocabDev d{};
+    d.cdesc = v->d_cdesc; d.childBegin = v->d_childBegin; d.child = v->d_child; d.word = v->d_word; d.weight = v->d_weight;
+    d.L = v->L; d.nnodes = v->nnodes;
+    return d;
+}
+
+static int bow_check(ssvio_matcher* m, const ssvio_vocab* v, int levelsup)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (!v) { set_error("null vocabulary (MatchByDBoW needs one: ssvio_vocab_create)"); return SSVIO_ERR_INVALID; }
+    if (v->device != m->device) { set_error("vocabulary lives on device %d, matcher on %d", v->device, m->device); return SSVIO_ERR_INVALID; }
+    if (levelsup < 0) { set_error("levelsup < 0"); return SSVIO_ERR_INVALID; }
+    return SSVIO_OK;
+}
+
+static int bow_grow(ssvio_matcher* m, size_t rows)
+{
+    hipStream_t s = m->stream;
+    int rc = grow(m->d_bowWord, m->bowWordCap, rows, s); if (rc) return rc;
+    rc = grow(m->d_bowNode, m->bowNodeCap, rows, s); if (rc) return rc;
+    rc = grow(m->d_bowWeight, m->bowWeightCap, rows, s); if (rc) return rc;
+    return grow(m->d_gnode, m->gnodeCap, rows, s);
+}
+
+// transform the rows of `nsets` descriptor sets; per-feature results land at rowBase + set * setStrideRows + i
+static void bow_run(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* d_desc, int setStrideRows, const int* d_counts, int nsets,
+                    int maxRows, int levelsup, size_t rowBase)
+{
+    BowArgs a{};
+    a.v = vocab_dev(v); a.nidLevel = v->L - levelsup;
+    a.desc = (const uint4*)d_desc; a.setStrideRows = setStrideRows; a.counts = d_counts; a.nsets = nsets;
+    a.word = m->d_bowWord + rowBase; a.node = m->d_bowNode + rowBase; a.weight = m->d_bowWeight + rowBase; a.gnode = m->d_gnode + rowBase;
+    ProfScope p(m->prof, "k_bow_transform", m->stream);
+    launch_bow_transform(a, maxRows, m->stream);
+}
+
+extern "C" {
+
+int ssvio_vocab_create(int device, int k, int L, int nnodes, const int32_t* parent, const uint8_t* desc, const double* weight,
+                       const int32_t* word, int scoring, int weighting, ssvio_vocab** out)
+{
+    if (!out) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    *out = nullptr;
+    if (!parent || !desc || !weight || !word || nnodes < 1 || k < 1 || L < 0) { set_error("bad vocabulary arguments"); return SSVIO_ERR_INVALID; }
+    if (nnodes > (1 << 30)) { set_error("too many nodes"); return SSVIO_ERR_INVALID; }
+    std::vector<int> begin((size_t)nnodes + 1, 0), child((size_t)std::max(nnodes - 1, 1)), fill((size_t)nnodes, 0);
+    for (int n = 1; n < nnodes; ++n) {
+        if (parent[n] < 0 || parent[n] >= n) { set_error("node %d: parent %d is not an earlier node", n, parent[n]); return SSVIO_ERR_INVALID; }
+        begin[(size_t)parent[n] + 1]++;
+    }
+    for (int n = 0; n < nnodes; ++n) {
+        if (begin[(size_t)n + 1] >= (1 << 20)) { set_error("node %d has 2^20 or more children", n); return SSVIO_ERR_INVALID; }
+        begin[(size_t)n + 1] += begin[n];
+    }
+    std::vector<uint8_t> cdesc((size_t)std::max(nnodes - 1, 1) * 32);
+    for (int n = 1; n < nnodes; ++n) {                      // ascending id inside every child list
+        const int c = begin[parent[n]] + fill[parent[n]]++;
+        child[c] = n;
+        memcpy(&cdesc[(size_t)c * 32], desc + (size_t)n * 32, 32);
+    }
+    const int rc = pick_device(device);
+    if (rc) return rc;
+    SSVIO_HIP(hipSetDevice(device));
+    ssvio_vocab* v = new ssvio_vocab();
+    v->device = device; v->k = k; v->L = L; v->nnodes = nnodes; v->scoring = scoring; v->weighting = weighting;
+    bool ok = hipMalloc(&v->d_cdesc, cdesc.size()) == hipSuccess && hipMalloc(&v->d_childBegin, begin.size() * sizeof(int)) == hipSuccess &&
+              hipMalloc(&v->d_child, child.size() * sizeof(int)) == hipSuccess && hipMalloc(&v->d_word, (size_t)nnodes * sizeof(int)) == hipSuccess &&
+              hipMalloc(&v->d_weight, (size_t)nnodes * sizeof(double)) == hipSuccess;
+    ok = ok && hipMemcpy(v->d_cdesc, cdesc.data(), cdesc.size(), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_childBegin, begin.data(), begin.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_child, child.data(), child.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_word, word, (size_t)nnodes * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_weight, weight, (size_t)nnodes * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { set_error("cannot place the vocabulary on the device"); ssvio_vocab_destroy(v); return SSVIO_ERR_HIP; }
+    *out = v;
+    return SSVIO_OK;
+}
+
+void ssvio_vocab_destroy(ssvio_vocab* v)
+{
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    (void)hipDeviceSynchronize();
+    dfree(v->d_cdesc); dfree(v->d_childBegin); dfree(v->d_child); dfree(v->d_word); dfree(v->d_weight);
+    delete v;
+}
+
+int ssvio_vocab_info(const ssvio_vocab* v, int* k, int* L, int* nnodes, int* scoring, int* weighting)
+{
+    if (!v) { set_error("null vocabulary"); return SSVIO_ERR_INVALID; }
+    if (k) *k = v->k; if (L) *L = v->L; if (nnodes) *nnodes = v->nnodes; if (scoring) *scoring = v->scoring; if (weighting) *weighting = v->weighting;
+    return SSVIO_OK;
+}
+
+int ssvio_bow_transform(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* desc, int n, int stride, int levelsup,
+                        int32_t* word, int32_t* node, double* weight)
+{
+    int rc = bow_check(m, v, levelsup); if (rc) return rc;
+    if (n < 0) { set_error("negative row count"); return SSVIO_ERR_INVALID; }
+    if (n == 0) return SSVIO_OK;
+    if (!desc || stride < 32) { set_error("bad descriptor matrix"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    size_t qcap = m->qRows * 32;
+    rc = grow(m->d_q, qcap, (size_t)n * 32, s); if (rc) return rc; m->qRows = qcap / 32;
+    rc = bow_grow(m, (size_t)n); if (rc) return rc;
+    rc = upload_rows(m->d_q, desc, n, stride, m->stageQ, s); if (rc) return rc;
+    const int counts[2] = {n, 0};
+    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    bow_run(m, v, m->d_q, 0, m->d_counts2, 1, n, levelsup, 0);
+    if (word) SSVIO_HIP(hipMemcpyAsync(word, m->d_bowWord, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (node) SSVIO_HIP(hipMemcpyAsync(node, m->d_bowNode, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (weight) SSVIO_HIP(hipMemcpyAsync(weight, m->d_bowWeight, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    m->prof.resolve();
+    m->lastBowQ = n; m->lastBowT = 0;
+    return SSVIO_OK;
+}
+
+int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, int nq, int qstride,
+                     const uint8_t* t, int nt, int tstride, int levelsup, ssvio_dmatch* out, int cap, int* n)
+{
+    int rc = bow_check(m, v, levelsup); if (rc) return rc;
+    if (n) *n = 0;
+    if (nq < 0 || nt < 0) { set_error("negative row count"); return SSVIO_ERR_INVALID; }
+    if (!(nq > 0 && nt > 0)) return SSVIO_OK;                          // src/FeatureMatching.cpp:61-63
+    if (!q || !t || !out || !n) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    if (qstride < 32 || tstride < 32) { set_error("descriptor stride < 32"); return SSVIO_ERR_INVALID; }
+    if (nt > (1 << 23) - 2 || nq > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
+    if (cap < nq) { set_error("output capacity %d < %d query rows", cap, nq); return SSVIO_ERR_CAPACITY; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
+    rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
+    rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
+    rc = bow_grow(m, (size_t)nq + nt); if (rc) return rc;
+    rc = grow(m->d_cand, m->candCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_keepNode, m->keepNodeCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_out, m->outCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
+    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
+    rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
+    const int counts[2] = {nq, nt};
+    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    bow_run(m, v, m->d_q, 0, m->d_counts2, 1, nq, levelsup, 0);               // ComputeBoWVector(desp1), :68
+    bow_run(m, v, m->d_t, 0, m->d_counts2 + 1, 1, nt, levelsup, (size_t)nq);  // ComputeBoWVector(desp2), :69
+    GroupedArgs g{};
+    g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + nq;
+    g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
+    g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq;
+    g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
+    {
+        ProfScope p(m->prof, "k_match_grouped", s);
+        launch_match_grouped(g, nq, 1, s);
+    }
+    int cnt = 0;
+    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+    *n = cnt;
+    m->prof.resolve();
+    m->lastBowQ = nq; m->lastBowT = nt;
+    return SSVIO_OK;
+}
+
+int ssvio_bow_last_transform(ssvio_matcher* m, int side, int32_t* word, int32_t* node, double* weight, int cap, int* n)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (side != 0 && side != 1) { set_error("side must be 0 (desp1) or 1 (desp2)"); return SSVIO_ERR_INVALID; }
+    const int rows = side ? m->lastBowT : m->lastBowQ;
+    const size_t base = side ? (size_t)m->lastBowQ : 0;
+    if (n) *n = rows;
+    if (rows == 0) return SSVIO_OK;
+    if (cap < rows) { set_error("capacity %d < %d rows", cap, rows); return SSVIO_ERR_CAPACITY; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    if (word) SSVIO_HIP(hipMemcpyAsync(word, m->d_bowWord + base, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+    if (node) SSVIO_HIP(hipMemcpyAsync(node, m->d_bowNode + base, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+    if (weight) SSVIO_HIP(hipMemcpyAsync(weight, m->d_bowWeight + base, (size_t)rows * 8, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    return SSVIO_OK;
+}
+
+int ssvio_match_dbow_batch_dev(ssvio_matcher* m, const ssvio_vocab* v, const void* d_desc, int set_stride_rows, int max_rows,
+                               const int32_t* d_counts, int nsets, const int32_t* pairs, int npairs, int levelsup,
+                               const void** d_matches, const int32_t** d_nmatches)
+{
+    int rc = bow_check(m, v, levelsup); if (rc) return rc;
+    if (!d_desc || !d_counts || !pairs || npairs <= 0 || nsets <= 0 || max_rows <= 0 || set_stride_rows < max_rows) { set_error("bad batch arguments"); return SSVIO_ERR_INVALID; }
+    if (max_rows > (1 << 23) - 2) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
+    for (int i = 0; i < 2 * npairs; ++i) if (pairs[i] < 0 || pairs[i] >= nsets) { set_error("pair %d names set %d of %d", i / 2, pairs[i], nsets); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    rc = upload_pairs(m, pairs, npairs); if (rc) return rc;
+    rc = bow_grow(m, (size_t)nsets * set_stride_rows); if (rc) return rc;
+    rc = grow(m->d_cand, m->candCap, (size_t)npairs * max_rows, s); if (rc) return rc;
+    rc = grow(m->d_keepNode, m->keepNodeCap, (size_t)npairs * max_rows, s); if (rc) return rc;
+    rc = grow(m->d_out, m->outCap, (size_t)npairs * max_rows, s); if (rc) return rc;
+    rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
+    bow_run(m, v, (const uint8_t*)d_desc, set_stride_rows, d_counts, nsets, max_rows, levelsup, 0);   // once per set, not per pair
+    GroupedArgs g{};
+    g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode;
+    g.qSetStrideRows = set_stride_rows; g.tSetStrideRows = set_stride_rows; g.qcounts = d_counts; g.tcounts = d_counts; g.pairs = m->d_pairs;
+    g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows;
+    g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
+    {
+        ProfScope p(m->prof, "k_match_grouped", s);
+        launch_match_grouped(g, max_rows, npairs, s);
+    }
+    m->lastPairs = npairs; m->lastMaxRows = max_rows;
+    m->lastBowQ = 0; m->lastBowT = 0;
+    if (d_matches) *d_matches = m->d_out;
+    if (d_nmatches) *d_nmatches = m->d_nout;
+    return SSVIO_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================
+// behind the matcher
+static int cam_dev(const ssvio_camera* cam, int w, int h, int stride_px, FrameCam& c)
+{
+    if (!cam) { set_error("null camera"); return SSVIO_ERR_INVALID; }
+    if (w <= 0 || h <= 0 || stride_px < w) { set_error("bad depth image geometry %dx%d stride %d", w, h, stride_px); return SSVIO_ERR_INVALID; }
+    c.cx = cam->cx; c.cy = cam->cy;
+    c.invFx = 1 / cam->fx; c.invFy = 1 / cam->fy;                    // include/Init.h:19-20
+    c.depthScale = cam->depth_scale; c.w = w; c.h = h; c.stridePx = stride_px;
+    return SSVIO_OK;
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// carve the assembled-list block of the handle into its seven arrays + counts
+static int assemble_outputs(ssvio_matcher* m, int npairs, int maxRows, AssembleArgs& a)
+{
+    const size_t rows = (size_t)npairs * maxRows;
+    const size_t s3 = align256(rows * 12), s2 = align256(rows * 8), sm = align256(rows * 16), sc = align256((size_t)npairs * 8);
+    int rc = grow(m->d_frameOut, m->frameOutCap, 4 * s3 + s2 + 2 * sm + sc, m->stream); if (rc) return rc;
+    uint8_t* p = m->d_frameOut;
+    a.last3d = (float*)p; p += s3; a.cur3d = (float*)p; p += s3; a.edgeLast3d = (float*)p; p += s3; a.edgeCur3d = (float*)p; p += s3;
+    a.cur2d = (float*)p; p += s2; a.preGood = (ssvio_dmatch*)p; p += sm; a.finalGood = (ssvio_dmatch*)p; p += sm; a.counts = (int*)p;
+    return SSVIO_OK;
+}
+
+extern "C" {
+
+int ssvio_get_3d_points(ssvio_matcher* m, const ssvio_keypoint* kps, int n, const uint16_t* depth, int w, int h, int stride_px,
+                        const ssvio_camera* cam, float* out)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    FrameCam c; int rc = cam_dev(cam, w, h, stride_px, c); if (rc) return rc;
+    if (n < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (n == 0) return SSVIO_OK;
+    if (!kps || !depth || !out) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t kb = align256((size_t)n * sizeof(ssvio_keypoint)), db = align256((size_t)h * stride_px * 2);
+    rc = grow(m->d_frameIn, m->frameInCap, kb + db, s); if (rc) return rc;
+    rc = grow(m->d_frameOut, m->frameOutCap, (size_t)n * 12, s); if (rc) return rc;
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, kps, (size_t)n * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn + kb, depth, (size_t)h * stride_px * 2, hipMemcpyHostToDevice, s));
+    {
+        ProfScope p(m->prof, "k_get_3d_points", s);
+        launch_get_3d_points((const ssvio_keypoint*)m->d_frameIn, n, (const uint16_t*)(m->d_frameIn + kb), c, (float*)m->d_frameOut, s);
+    }
+    SSVIO_HIP(hipMemcpyAsync(out, m->d_frameOut, (size_t)n * 12, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_assemble_correspondences(ssvio_matcher* m, const ssvio_dmatch* matches, int nm,
+                                   const ssvio_keypoint* last_kps, int nlast, const uint16_t* last_depth,
+                                   const ssvio_keypoint* cur_kps, int ncur, const uint16_t* cur_depth,
+                                   int w, int h, int stride_px, const ssvio_camera* cam,
+                                   float* last3d, float* cur2d, float* cur3d, ssvio_dmatch* pre_good, int* n_pre,
+                                   float* edge_last3d, float* edge_cur3d, ssvio_dmatch* final_good, int* n_final)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    FrameCam c; int rc = cam_dev(cam, w, h, stride_px, c); if (rc) return rc;
+    if (n_pre) *n_pre = 0;
+    if (n_final) *n_final = 0;
+    if (nm < 0 || nlast < 0 || ncur < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (nm == 0) return SSVIO_OK;                                   // the loop of src/Odometry.cpp:44 does not run
+    if (!matches || !last_kps || !cur_kps || !last_depth || !cur_depth || !last3d || !cur2d || !cur3d || !pre_good || !n_pre ||
+        !edge_last3d || !edge_cur3d || !final_good || !n_final) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    for (int i = 0; i < nm; ++i)
+        if (matches[i].trainIdx < 0 || matches[i].trainIdx >= nlast || matches[i].queryIdx < 0 || matches[i].queryIdx >= ncur) {
+            set_error("match %d (query %d, train %d) is outside the keypoint lists (%d, %d)", i, matches[i].queryIdx, matches[i].trainIdx, ncur, nlast);
+            return SSVIO_ERR_INVALID;
+        }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const int kpStride = std::max(std::max(nlast, ncur), 1);
+    const size_t depthPx = (size_t)h * stride_px;
+    const size_t mb = align256((size_t)nm * 16), kb = align256((size_t)2 * kpStride * sizeof(ssvio_keypoint)), db = align256(2 * depthPx * 2);
+    rc = grow(m->d_frameIn, m->frameInCap, mb + kb + db + 256, s); if (rc) return rc;
+    uint8_t* d_m = m->d_frameIn; uint8_t* d_k = d_m + mb; uint8_t* d_d = d_k + kb; int* d_c = (int*)(d_d + db);   // {nm, ncur, nlast}
+    SSVIO_HIP(hipMemcpyAsync(d_m, matches, (size_t)nm * 16, hipMemcpyHostToDevice, s));
+    if (ncur) SSVIO_HIP(hipMemcpyAsync(d_k, cur_kps, (size_t)ncur * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));       // set 0 = current
+    if (nlast) SSVIO_HIP(hipMemcpyAsync(d_k + (size_t)kpStride * sizeof(ssvio_keypoint), last_kps, (size_t)nlast * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(d_d, cur_depth, depthPx * 2, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(d_d + depthPx * 2, last_depth, depthPx * 2, hipMemcpyHostToDevice, s));
+    const int cnts[3] = {nm, ncur, nlast};
+    SSVIO_HIP(hipMemcpyAsync(d_c, cnts, sizeof cnts, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipStreamSynchronize(s));                             // `cnts` is a stack array
+    AssembleArgs a{};
+    a.matches = (const ssvio_dmatch*)d_m; a.nmatches = d_c; a.maxRows = nm; a.pairs = nullptr;
+    a.kps = (const ssvio_keypoint*)d_k; a.kpStride = kpStride; a.kpCounts = d_c + 1;
+    a.depth = (const uint16_t*)d_d; a.depthFrameStride = depthPx; a.cam = c;
+    rc = assemble_outputs(m, 1, nm, a); if (rc) return rc;
+    {
+        ProfScope p(m->prof, "k_assemble", s);
+        launch_assemble(a, 1, s);
+    }
+    int got[2] = {0, 0};
+    SSVIO_HIP(hipMemcpyAsync(got, a.counts, sizeof got, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    const size_t np = (size_t)got[0], nf = (size_t)got[1];
+    if (np) {
+        SSVIO_HIP(hipMemcpyAsync(last3d, a.last3d, np * 12, hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(cur2d, a.cur2d, np * 8, hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(cur3d, a.cur3d, np * 12, hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(pre_good, a.preGood, np * 16, hipMemcpyDeviceToHost, s));
+    }
+    if (nf) {
+        SSVIO_HIP(hipMemcpyAsync(edge_last3d, a.edgeLast3d, nf * 12, hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(edge_cur3d, a.edgeCur3d, nf * 12, hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(final_good, a.finalGood, nf * 16, hipMemcpyDeviceToHost, s));
+    }
+    SSVIO_HIP(hipStreamSynchronize(s));
+    *n_pre = got[0]; *n_final = got[1];
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_assemble_batch_dev(ssvio_matcher* m, const void* d_matches, const int32_t* d_nmatches, int max_rows,
+                             const int32_t* pairs, int npairs, const void* d_kps, int kp_stride, const int32_t* d_kpcounts,
+                             const void* d_depth, size_t depth_frame_stride, int w, int h, int stride_px,
+                             const ssvio_camera* cam, ssvio_correspondences_dev* out)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    FrameCam c; int rc = cam_dev(cam, w, h, stride_px, c); if (rc) return rc;
+    if (!d_matches || !d_nmatches || !pairs || !d_kps || !d_kpcounts || !d_depth || !out || npairs <= 0 || max_rows <= 0 || kp_stride <= 0 ||
+        depth_frame_stride < (size_t)h * stride_px) { set_error("bad batch arguments"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    rc = upload_pairs(m, pairs, npairs); if (rc) return rc;
+    AssembleArgs a{};
+    a.matches = (const ssvio_dmatch*)d_matches; a.nmatches = d_nmatches; a.maxRows = max_rows; a.pairs = m->d_pairs;
+    a.kps = (const ssvio_keypoint*)d_kps; a.kpStride = kp_stride; a.kpCounts = d_kpcounts;
+    a.depth = (const uint16_t*)d_depth; a.depthFrameStride = depth_frame_stride; a.cam = c;
+    rc = assemble_outputs(m, npairs, max_rows, a); if (rc) return rc;
+    {
+        ProfScope p(m->prof, "k_assemble", m->stream);
+        launch_assemble(a, npairs, m->stream);
+    }
+    out->last3d = a.last3d; out->cur2d = a.cur2d; out->cur3d = a.cur3d; out->pre_good = a.preGood;
+    out->edge_last3d = a.edgeLast3d; out->edge_cur3d = a.edgeCur3d; out->final_good = a.finalGood; out->counts = a.counts;
+    return SSVIO_OK;
+}
+
+// index map over a DMatch list on the device: table[key] = first position (0xFFFFFFFF = none)
+static int first_index_table(ssvio_matcher* m, const ssvio_dmatch* d_v, int n, int useTrain, int tableSize)
+{
+    hipStream_t s = m->stream;
+    int rc = grow(m->d_table, m->tableCap, (size_t)std::max(tableSize, 1), s); if (rc) return rc;
+    SSVIO_HIP(hipMemsetAsync(m->d_table, 0xFF, (size_t)std::max(tableSize, 1) * 4, s));
+    ProfScope p(m->prof, "k_first_index", s);
+    launch_first_index(d_v, n, useTrain, m->d_table, tableSize, s);
+    return SSVIO_OK;
+}
+
+int ssvio_track_map_points(ssvio_matcher* m, const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, int ncur,
+                           ssvio_dmatch* out, int cap, int* n)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (n) *n = 0;
+    if (nlast < 0 || ncur < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (nlast == 0 || ncur == 0) return SSVIO_OK;                    // no pair can meet: last_match_vec becomes empty (src/Map.cpp:121-122)
+    if (!last || !cur || !out || !n) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    if (cap < nlast) { set_error("output capacity %d < %d", cap, nlast); return SSVIO_ERR_CAPACITY; }
+    int maxKey = -1;                                                 // the map covers the keys the join can ask for
+    for (int i = 0; i < nlast; ++i) maxKey = std::max(maxKey, last[i].queryIdx);
+    if (maxKey < 0) return SSVIO_OK;
+    if (maxKey >= (1 << 28)) { set_error("queryIdx %d too large for an index map", maxKey); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t lb = align256((size_t)nlast * 16), cb = align256((size_t)ncur * 16);
+    int rc = grow(m->d_frameIn, m->frameInCap, lb + cb, s); if (rc) return rc;
+    rc = grow(m->d_out, m->outCap, (size_t)nlast, s); if (rc) return rc;
+    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, last, (size_t)nlast * 16, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn + lb, cur, (size_t)ncur * 16, hipMemcpyHostToDevice, s));
+    rc = first_index_table(m, (const ssvio_dmatch*)(m->d_frameIn + lb), ncur, 1, maxKey + 1); if (rc) return rc;
+    {
+        ProfScope p(m->prof, "k_track", s);
+        launch_track((const ssvio_dmatch*)m->d_frameIn, nlast, (const ssvio_dmatch*)(m->d_frameIn + lb), m->d_table, maxKey + 1, m->d_out, m->d_nout, s);
+    }
+    int cnt = 0;
+    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+    *n = cnt;
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_in_match_vec(ssvio_matcher* m, const ssvio_dmatch* vec, int n, int nkp, int32_t* out)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (n < 0 || nkp < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (nkp == 0) return SSVIO_OK;
+    if (!out || (n > 0 && !vec)) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    int rc = grow(m->d_frameIn, m->frameInCap, (size_t)std::max(n, 1) * 16, s); if (rc) return rc;
+    if (n) SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, vec, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    rc = first_index_table(m, (const ssvio_dmatch*)m->d_frameIn, n, 0, nkp); if (rc) return rc;
+    SSVIO_HIP(hipMemcpyAsync(out, m->d_table, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));    // 0xFFFFFFFF reads as -1
+    SSVIO_HIP(hipStreamSynchronize(s));
+    m->prof.resolve();
     return SSVIO_OK;
 }
 

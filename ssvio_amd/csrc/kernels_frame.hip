@@ -1,0 +1,144 @@
+// kernels_frame.hip -- the steps right behind the matcher, on gfx950.
+//
+//   k_get_3d_points   Frame::Get3DPoint (src/Frame.cpp:93-108) for a list of keypoints: depth gather + pinhole inverse
+//   k_assemble        Odometry::OptimizeTransform's two filter loops (src/Odometry.cpp:44-64, :94-108): the PnP input
+//                     lists and the ICP edge lists, both in match order (ordered compaction by workgroup scans)
+//   k_first_index     index map "key -> first position in a DMatch list" (atomicMin), which replaces the linear
+//                     searches of Map::InMatchVec (src/Map.cpp:151-162) and Map::TrackMapPoints (:100-123)
+//   k_track           TrackMapPoints' join through that map, emitted in last_match_vec order
+// Float code is single precision, left to right, no contraction (this library is built with -ffp-contract=off).
+#include "match.h"
+#include <cfloat>
+
+namespace ssvio {
+
+// Frame::Get3DPoint.  Mat::at<ushort>(pos_y, pos_x) with float arguments truncates both toward zero (:101); the
+// reference does not check the pixel against the image, the clamp only keeps a corrupt keypoint from faulting.
+__device__ __forceinline__ void get_3d_point(const ssvio_keypoint& kp, const uint16_t* depth, const FrameCam& c, float out[3])
+{
+    const float pos_x = kp.x, pos_y = kp.y;
+    const int px = min(max((int)pos_x, 0), c.w - 1), py = min(max((int)pos_y, 0), c.h - 1);
+    const float d = (float)depth[(size_t)py * c.stridePx + px] * c.depthScale;
+    out[0] = (pos_x - c.cx) * d * c.invFx;                            // :103
+    out[1] = (pos_y - c.cy) * d * c.invFy;                            // :104
+    out[2] = d;                                                       // :105
+}
+
+__global__ __launch_bounds__(256) void k_get_3d_points(const ssvio_keypoint* kps, int n, const uint16_t* depth, FrameCam c, float* out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float p[3];
+    get_3d_point(kps[i], depth, c, p);
+    out[3 * i] = p[0]; out[3 * i + 1] = p[1]; out[3 * i + 2] = p[2];
+}
+
+void launch_get_3d_points(const ssvio_keypoint* kps, int n, const uint16_t* depth, const FrameCam& c, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_get_3d_points, dim3((n + 255) / 256), dim3(256), 0, s, kps, n, depth, c, out);
+}
+
+// one workgroup per frame pair; match i of the pair is handled by thread i % 256 in pass i / 256
+__global__ __launch_bounds__(256) void k_assemble(AssembleArgs a)
+{
+    __shared__ int wsum[4];
+    const int pair = blockIdx.x;
+    const int curSet = a.pairs ? a.pairs[2 * pair] : 0, lastSet = a.pairs ? a.pairs[2 * pair + 1] : 1;
+    const int nm = min(a.nmatches[pair], a.maxRows);
+    const ssvio_dmatch* M = a.matches + (size_t)pair * a.maxRows;
+    const ssvio_keypoint* lastK = a.kps + (size_t)lastSet * a.kpStride;
+    const ssvio_keypoint* curK = a.kps + (size_t)curSet * a.kpStride;
+    const uint16_t* lastD = a.depth + (size_t)lastSet * a.depthFrameStride;
+    const uint16_t* curD = a.depth + (size_t)curSet * a.depthFrameStride;
+    const int nLast = a.kpCounts[lastSet], nCur = a.kpCounts[curSet];
+    const size_t ob = (size_t)pair * a.maxRows;
+    int nPre = 0, nFin = 0;
+    for (int i0 = 0; i0 < nm; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        bool pre = false, fin = false;
+        ssvio_dmatch m = {0, 0, 0, 0.f};
+        float lp[3] = {0.f, 0.f, 0.f}, cp[3] = {0.f, 0.f, 0.f}, c2x = 0.f, c2y = 0.f;
+        if (i < nm) {
+            m = M[i];
+            if (m.trainIdx >= 0 && m.trainIdx < nLast && m.queryIdx >= 0 && m.queryIdx < nCur) {   // indices a matcher emits
+                get_3d_point(lastK[m.trainIdx], lastD, a.cam, lp);                     // src/Odometry.cpp:50
+                pre = lp[2] >= a.cam.depthScale;                                       // :51
+                const ssvio_keypoint ck = curK[m.queryIdx];
+                c2x = ck.x; c2y = ck.y;                                                // :54-55
+                get_3d_point(ck, curD, a.cam, cp);                                     // :59
+                fin = pre && cp[2] >= a.cam.depthScale;                                // :102
+            }
+        }
+        int totPre, totFin;
+        const int oPre = block_excl_scan(pre ? 1 : 0, wsum, totPre);
+        const int oFin = block_excl_scan(fin ? 1 : 0, wsum, totFin);
+        if (pre) {
+            const size_t o = ob + nPre + oPre;
+            a.last3d[3 * o] = lp[0]; a.last3d[3 * o + 1] = lp[1]; a.last3d[3 * o + 2] = lp[2];
+            a.cur2d[2 * o] = c2x; a.cur2d[2 * o + 1] = c2y;
+            a.cur3d[3 * o] = cp[0]; a.cur3d[3 * o + 1] = cp[1]; a.cur3d[3 * o + 2] = cp[2];
+            a.preGood[o] = m;
+        }
+        if (fin) {
+            const size_t o = ob + nFin + oFin;
+            a.edgeLast3d[3 * o] = lp[0]; a.edgeLast3d[3 * o + 1] = lp[1]; a.edgeLast3d[3 * o + 2] = lp[2];
+            a.edgeCur3d[3 * o] = cp[0]; a.edgeCur3d[3 * o + 1] = cp[1]; a.edgeCur3d[3 * o + 2] = cp[2];
+            a.finalGood[o] = m;
+        }
+        nPre += totPre; nFin += totFin;
+    }
+    if (threadIdx.x == 0) { a.counts[2 * pair] = nPre; a.counts[2 * pair + 1] = nFin; }
+}
+
+void launch_assemble(const AssembleArgs& a, int npairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_assemble, dim3(npairs), dim3(256), 0, s, a);
+}
+
+// table[key] = min position j with field(v[j]) == key; table starts at 0xFFFFFFFF (= -1 as int32: "not found")
+__global__ __launch_bounds__(256) void k_first_index(const ssvio_dmatch* v, int n, int useTrain, uint32_t* table, int tableSize)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int key = useTrain ? v[j].trainIdx : v[j].queryIdx;
+    if (key >= 0 && key < tableSize) atomicMin(&table[key], (uint32_t)j);
+}
+
+// Map::TrackMapPoints (src/Map.cpp:100-123): one workgroup, output in last_match_vec order
+__global__ __launch_bounds__(256) void k_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, const uint32_t* table,
+                                               int tableSize, ssvio_dmatch* out, int* nout)
+{
+    __shared__ int wsum[4];
+    int written = 0;
+    for (int i0 = 0; i0 < nlast; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        uint32_t j = 0xFFFFFFFFu; int train = 0;
+        if (i < nlast) {
+            const ssvio_dmatch l = last[i];
+            train = l.trainIdx;
+            if (l.queryIdx >= 0 && l.queryIdx < tableSize) j = table[l.queryIdx];        // :108, first j
+        }
+        const bool keep = j != 0xFFFFFFFFu;
+        int total;
+        const int off = block_excl_scan(keep ? 1 : 0, wsum, total);
+        if (keep) {
+            ssvio_dmatch m; m.queryIdx = cur[j].queryIdx; m.trainIdx = train; m.imgIdx = -1; m.distance = FLT_MAX;   // cv::DMatch() defaults
+            out[written + off] = m;
+        }
+        written += total;
+    }
+    if (threadIdx.x == 0) *nout = written;
+}
+
+void launch_first_index(const ssvio_dmatch* v, int n, int useTrain, uint32_t* table, int tableSize, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(k_first_index, dim3((n + 255) / 256), dim3(256), 0, s, v, n, useTrain, table, tableSize);
+}
+
+void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, const uint32_t* table, int tableSize,
+                  ssvio_dmatch* out, int* nout, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_track, dim3(1), dim3(256), 0, s, last, nlast, cur, table, tableSize, out, nout);
+}
+
+}  // namespace ssvio

@@ -12,16 +12,6 @@
 namespace ssvio {
 
 constexpr int kTT = 128;                 // train rows per LDS tile
-constexpr unsigned kKeyInit = 0xFFFFFFFFu;
-
-// median of three unsigned values in one VALU instruction
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // d += popcount(x): the accumulating form of v_bcnt_u32_b32 (one instruction per dword; left to itself the
 // compiler splits the chain into bcnt(x, 0) + v_add3_u32, 3 more instructions per descriptor pair)
 __device__ __forceinline__ void bcnt_acc(uint32_t& d, uint32_t x)
@@ -162,21 +152,6 @@ __global__ __launch_bounds__(256) void k_match_merge(uint2* partial, int nChunks
     uint32_t k1, k2;
     merge_chunks(P, nChunks, maxRows, i, k1, k2);
     P[i] = make_uint2(k1, k2);
-}
-
-__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total)
-{
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    __syncthreads();
-    if (lane == 63) wsum[wid] = incl;
-    __syncthreads();
-    int base = 0; total = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { if (i < wid) base += wsum[i]; total += wsum[i]; }
-    return base + incl - v;
 }
 
 // one workgroup per pair: filter and emit DMatch rows in ascending query order.

@@ -37,7 +37,86 @@ struct ProjectArgs {
 };
 void launch_project(const ProjectArgs& a, hipStream_t s);
 
+// DBoW3 vocabulary tree on the device (MatchByDBoW, src/FeatureMatching.cpp:58-125, :192-208)
+struct VocabDev {
+    const uint4* cdesc;        // [nnodes-1][2] uint4: node descriptors in child-list order (the children of a node are contiguous)
+    const int* childBegin;     // [nnodes+1] CSR offsets into child / cdesc
+    const int* child;          // [nnodes-1] node ids, children of a node in ascending id
+    const int* word;           // [nnodes] word id of a leaf
+    const double* weight;      // [nnodes]
+    int L, nnodes;
+};
+struct BowArgs {
+    VocabDev v; int nidLevel;                  // L - levelsup
+    const uint4* desc; int setStrideRows; const int* counts; int nsets;
+    int32_t* word; int32_t* node; double* weight;   // per feature, same row indexing as desc
+    int32_t* gnode;                            // node id, or -1 for a stopped word (weight <= 0): the grouping key
+};
+void launch_bow_transform(const BowArgs& a, int maxRows, hipStream_t s);
+
+// grouped 2-NN of MatchByDBoW: candidates of query i = train rows with the same grouping key
+struct GroupedArgs {
+    const uint4* qdesc; const uint4* tdesc; const int32_t* qgnode; const int32_t* tgnode;
+    int qSetStrideRows, tSetStrideRows; const int* qcounts; const int* tcounts; const int* pairs;
+    int threshold; float nnRatio; int maxRows;
+    ssvio_dmatch* cand; int32_t* keepNode;     // [pair][maxRows]: candidate match; node id if it is kept else -1
+    ssvio_dmatch* out; int* nout;              // [pair][maxRows], [pair]
+};
+void launch_match_grouped(const GroupedArgs& a, int maxQ, int npairs, hipStream_t s);
+
+// behind the matcher: Frame::Get3DPoint, correspondence assembly, match chaining
+struct FrameCam { float cx, cy, invFx, invFy, depthScale; int w, h, stridePx; };
+struct AssembleArgs {
+    const ssvio_dmatch* matches; const int* nmatches; int maxRows;      // [pair][maxRows], [pair]
+    const int* pairs;                                                   // (current set, last set) per pair; null = (0, 1)
+    const ssvio_keypoint* kps; int kpStride; const int* kpCounts;       // set s: kps + s * kpStride, kpCounts[s] entries
+    const uint16_t* depth; size_t depthFrameStride;                     // set s: depth + s * depthFrameStride (pixels)
+    FrameCam cam;
+    float* last3d; float* cur2d; float* cur3d; ssvio_dmatch* preGood;   // [pair][maxRows] each
+    float* edgeLast3d; float* edgeCur3d; ssvio_dmatch* finalGood;
+    int* counts;                                                        // [pair][2] = {n_pre, n_final}
+};
+void launch_get_3d_points(const ssvio_keypoint* kps, int n, const uint16_t* depth, const FrameCam& c, float* out, hipStream_t s);
+void launch_assemble(const AssembleArgs& a, int npairs, hipStream_t s);
+void launch_first_index(const ssvio_dmatch* v, int n, int useTrain, uint32_t* table, int tableSize, hipStream_t s);
+void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, const uint32_t* table, int tableSize,
+                  ssvio_dmatch* out, int* nout, hipStream_t s);
+
 void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);
 void launch_finalize(const FinalizeArgs& a, int npairs, int maxQ, int maxT, hipStream_t s);
+
+#if defined(__HIPCC__)
+constexpr unsigned kKeyInit = 0xFFFFFFFFu;     // "no candidate yet" in the (dist << 23 | trainIdx) key order
+
+// median of three unsigned values in one VALU instruction
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t hamming256(const uint4 alo, const uint4 ahi, const uint4 blo, const uint4 bhi)
+{
+    return __popc(alo.x ^ blo.x) + __popc(alo.y ^ blo.y) + __popc(alo.z ^ blo.z) + __popc(alo.w ^ blo.w) +
+           __popc(ahi.x ^ bhi.x) + __popc(ahi.y ^ bhi.y) + __popc(ahi.z ^ bhi.z) + __popc(ahi.w ^ bhi.w);
+}
+
+// exclusive scan of v over a 256-thread workgroup (wsum: 4 ints of LDS); total = sum over the workgroup
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    __syncthreads();
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    int base = 0; total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (i < wid) base += wsum[i]; total += wsum[i]; }
+    return base + incl - v;
+}
+#endif
 
 }  // namespace ssvio

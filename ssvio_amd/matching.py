@@ -4,17 +4,20 @@ match vectors are structured arrays with cv::DMatch's layout."""
 import ctypes as C
 import numpy as np
 from . import _lib as L
+from .vocabulary import Vocabulary
 
 
 class FeatureMatching:
     def __init__(self, voc_dataset=None, config=None, device=0):
         """include/FeatureMatching.h:18, src/FeatureMatching.cpp:6-12.  `config` maps
-        "Threshold"/"NNRatio" (config/default_conf.yaml:26-27).  The DBoW3 vocabulary named by
-        voc_dataset belongs to MatchByDBoW, which is outside this library's scope."""
+        "Threshold"/"NNRatio" (config/default_conf.yaml:26-27).  voc_dataset: a Vocabulary, the path of a text
+        vocabulary (vocabulary.py), or None (then MatchByDBoW raises)."""
         config = config or {}
         self.mTh_ = int(config.get("Threshold", 50))
         self.mNNRatio_ = float(config.get("NNRatio", 0.6))
-        self.voc_dataset = voc_dataset
+        self.device = device
+        self.mVoc_ = Vocabulary.load_txt(voc_dataset) if isinstance(voc_dataset, (str, bytes)) else voc_dataset
+        self.mBowVec1_ = self.mBowVec2_ = self.mFeatVec1_ = self.mFeatVec2_ = None
         self._h = C.c_void_p()
         L.check(L.lib().ssvio_matcher_create(self.mTh_, self.mNNRatio_, device, C.byref(self._h)))
 
@@ -71,10 +74,99 @@ class FeatureMatching:
         m = out[:n.value].copy()
         return len(m) > 0, m
 
-    def MatchByDBoW(self, desp1, desp2):
-        """include/FeatureMatching.h:27: needs the DBoW3 vocabulary (un-vendored library, blob
-        missing from the reference tree) -- out of scope, never silently emulated."""
-        raise NotImplementedError("MatchByDBoW needs DBoW3 + its vocabulary; out of scope for this library")
+    def _voc(self):
+        if self.mVoc_ is None:
+            raise ValueError("MatchByDBoW / ComputeBoWVector need a vocabulary (FeatureMatching(voc_dataset=...))")
+        return self.mVoc_.handle(self.device)
+
+    def ComputeBoWVector(self, desp, levelsup=4):
+        """src/FeatureMatching.cpp:192-208 -> (bowVec, featVec, (word, node, weight) per feature)"""
+        d, n, st = self._rows(desp)
+        word = np.zeros(n, np.int32); node = np.zeros(n, np.int32); weight = np.zeros(n, np.float64)
+        L.check(L.lib().ssvio_bow_transform(self._h, self._voc(), L.ptr(d), n, st, levelsup, L.ptr(word), L.ptr(node), L.ptr(weight)))
+        return self.mVoc_.bow_vector(word, weight), Vocabulary.feature_vector(node, weight), (word, node, weight)
+
+    def MatchByDBoW(self, desp1, desp2, matches=None, levelsup=4):
+        """include/FeatureMatching.h:27, src/FeatureMatching.cpp:58-125 -> (bool, matches).  With either matrix empty the
+        reference returns false BEFORE clearing `matches` (:61-65): the list passed in comes back unchanged."""
+        q, nq, qs = self._rows(desp1); t, nt, ts = self._rows(desp2)
+        if not (nq > 0 and nt > 0):
+            return False, (matches if matches is not None else np.zeros(0, L.DM_DTYPE))
+        voc = self._voc()
+        out = np.zeros(nq, L.DM_DTYPE); n = C.c_int(0)
+        L.check(L.lib().ssvio_match_dbow(self._h, voc, L.ptr(q), nq, qs, L.ptr(t), nt, ts, levelsup, L.ptr(out), nq, C.byref(n)))
+        sides = []
+        for side, rows in ((0, nq), (1, nt)):                       # mBowVec*_ / mFeatVec*_ (include/FeatureMatching.h:46-49)
+            word = np.zeros(rows, np.int32); node = np.zeros(rows, np.int32); weight = np.zeros(rows, np.float64); got = C.c_int(0)
+            L.check(L.lib().ssvio_bow_last_transform(self._h, side, L.ptr(word), L.ptr(node), L.ptr(weight), rows, C.byref(got)))
+            sides.append((self.mVoc_.bow_vector(word, weight), Vocabulary.feature_vector(node, weight)))
+        (self.mBowVec1_, self.mFeatVec1_), (self.mBowVec2_, self.mFeatVec2_) = sides
+        m = out[:n.value].copy()
+        return len(m) > 0, m
+
+    def match_dbow_batch_dev(self, d_desc, set_stride_rows, max_rows, d_counts, nsets, pairs, levelsup=4):
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        dm, dn = C.c_void_p(), C.c_void_p()
+        L.check(L.lib().ssvio_match_dbow_batch_dev(self._h, self._voc(), L.ptr(d_desc), set_stride_rows, max_rows, L.ptr(d_counts), nsets,
+                                                   L.ptr(pairs), len(pairs), levelsup, C.byref(dm), C.byref(dn)))
+        self._last = (len(pairs), max_rows)
+        return dm.value, dn.value
+
+    # ---- behind the matcher (SURVEY.md §8 f2, f3)
+    @staticmethod
+    def _cam(cam):
+        c = np.ascontiguousarray(cam, np.float32).reshape(5)        # cx, cy, fx, fy, DepthScale/65535
+        return c
+
+    def Get3DPoints(self, kps, depth, cam):
+        """Frame::Get3DPoint (src/Frame.cpp:93-108) for every keypoint -> [n][3] float32"""
+        kps = np.ascontiguousarray(kps, L.KP_DTYPE); depth = np.ascontiguousarray(depth, np.uint16); c = self._cam(cam)
+        out = np.zeros((len(kps), 3), np.float32)
+        L.check(L.lib().ssvio_get_3d_points(self._h, L.ptr(kps), len(kps), L.ptr(depth), depth.shape[1], depth.shape[0], depth.shape[1],
+                                            L.ptr(c), L.ptr(out)))
+        return out
+
+    def AssembleCorrespondences(self, matches, last_kps, last_depth, cur_kps, cur_depth, cam):
+        """the two filter loops of Odometry::OptimizeTransform (src/Odometry.cpp:44-64, :94-108)"""
+        m = np.ascontiguousarray(matches, L.DM_DTYPE); nm = len(m)
+        lk = np.ascontiguousarray(last_kps, L.KP_DTYPE); ck = np.ascontiguousarray(cur_kps, L.KP_DTYPE)
+        ld = np.ascontiguousarray(last_depth, np.uint16); cd = np.ascontiguousarray(cur_depth, np.uint16); c = self._cam(cam)
+        if ld.shape != cd.shape:
+            raise ValueError("depth images differ in size")
+        cap = max(nm, 1)
+        last3d = np.zeros((cap, 3), np.float32); cur2d = np.zeros((cap, 2), np.float32); cur3d = np.zeros((cap, 3), np.float32)
+        pre = np.zeros(cap, L.DM_DTYPE); el = np.zeros((cap, 3), np.float32); ec = np.zeros((cap, 3), np.float32); fin = np.zeros(cap, L.DM_DTYPE)
+        a, b = C.c_int(0), C.c_int(0)
+        L.check(L.lib().ssvio_assemble_correspondences(self._h, L.ptr(m), nm, L.ptr(lk), len(lk), L.ptr(ld), L.ptr(ck), len(ck), L.ptr(cd),
+                                                       ld.shape[1], ld.shape[0], ld.shape[1], L.ptr(c),
+                                                       L.ptr(last3d), L.ptr(cur2d), L.ptr(cur3d), L.ptr(pre), C.byref(a),
+                                                       L.ptr(el), L.ptr(ec), L.ptr(fin), C.byref(b)))
+        a, b = a.value, b.value
+        return {"last3d": last3d[:a].copy(), "cur2d": cur2d[:a].copy(), "cur3d": cur3d[:a].copy(), "pre_good": pre[:a].copy(),
+                "edge_last3d": el[:b].copy(), "edge_cur3d": ec[:b].copy(), "final_good": fin[:b].copy()}
+
+    def assemble_batch_dev(self, d_matches, d_nmatches, max_rows, pairs, d_kps, kp_stride, d_kpcounts, d_depth, depth_frame_stride,
+                           w, h, stride_px, cam):
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2); c = self._cam(cam)
+        out = L.CorrespondencesDev()
+        L.check(L.lib().ssvio_assemble_batch_dev(self._h, L.ptr(d_matches), L.ptr(d_nmatches), max_rows, L.ptr(pairs), len(pairs),
+                                                 L.ptr(d_kps), kp_stride, L.ptr(d_kpcounts), L.ptr(d_depth), depth_frame_stride,
+                                                 w, h, stride_px, L.ptr(c), C.byref(out)))
+        return out
+
+    def TrackMapPoints(self, last_match_vec, this_match_vec):
+        """Map::TrackMapPoints (src/Map.cpp:100-123) -> the new last_match_vec"""
+        last = np.ascontiguousarray(last_match_vec, L.DM_DTYPE); cur = np.ascontiguousarray(this_match_vec, L.DM_DTYPE)
+        out = np.zeros(max(len(last), 1), L.DM_DTYPE); n = C.c_int(0)
+        L.check(L.lib().ssvio_track_map_points(self._h, L.ptr(last), len(last), L.ptr(cur), len(cur), L.ptr(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def InMatchVec(self, match_vec, nkp):
+        """Map::InMatchVec (src/Map.cpp:151-162) for keypoints 0..nkp-1"""
+        v = np.ascontiguousarray(match_vec, L.DM_DTYPE)
+        out = np.zeros(nkp, np.int32)
+        L.check(L.lib().ssvio_in_match_vec(self._h, L.ptr(v), len(v), nkp, L.ptr(out)))
+        return out
 
     def knn2_raw(self, desp1, desp2):
         q, nq, qs = self._rows(desp1); t, nt, ts = self._rows(desp2)

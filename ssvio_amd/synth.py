@@ -146,3 +146,52 @@ def descriptor_sets(seed, nq, nt, flip_p=0.08, inlier_frac=0.7):
     fresh = rng.bytes(nq * 32).reshape(nq, 32)
     query[~inl] = fresh[~inl]
     return np.ascontiguousarray(query), np.ascontiguousarray(train)
+
+
+def vocabulary_tables(seed, k=10, L=3, flip0=0.30, early_leaf_p=0.0, stop_p=0.05):
+    """node table of a synthetic DBoW3-style vocabulary tree (depth-first ids like DBoW3's HKmeansStep): a child's
+    descriptor is its parent's with a share of bits flipped that halves per level (clusters inside clusters);
+    early_leaf_p turns inner nodes into leaves early, stop_p gives leaves weight 0 (stopped words).
+    Returns parent[int32], desc[n][32], weight[float64]."""
+    rng = Rng(seed)
+    parent = [-1]; desc = [rng.bytes(32)]; level = [0]
+    stack = [0]
+    while stack:
+        n = stack.pop()
+        if level[n] >= L:
+            continue
+        if n != 0 and early_leaf_p > 0 and rng.uniform(1)[0] < early_leaf_p:
+            continue
+        p = flip0 / (2 ** level[n])
+        kids = []
+        for _ in range(k):
+            flips = rng.uniform(256) < p
+            d = desc[n] ^ np.packbits(flips, bitorder="little")
+            parent.append(n); desc.append(d); level.append(level[n] + 1); kids.append(len(parent) - 1)
+        stack.extend(reversed(kids))        # depth first, first child first
+    # depth-first creation gives parent[n] < n but the ids above are breadth-inside-depth; both satisfy the table's contract
+    n = len(parent)
+    w = 0.5 + 4.0 * rng.uniform(n)
+    w[rng.uniform(n) < stop_p] = 0.0
+    par = np.array(parent, np.int32); par[0] = -1
+    return par, np.array(desc, np.uint8), w
+
+
+def descriptors_near_leaves(seed, n, parent, desc, flip_p=0.03):
+    """n descriptors: random leaves of the tree with bits flipped w.p. flip_p"""
+    rng = Rng(seed)
+    leaf = np.ones(len(parent), bool); leaf[parent[1:]] = False
+    ids = np.flatnonzero(leaf)
+    pick = ids[rng.randint(0, len(ids), n)]
+    flips = rng.uniform(n * 256).reshape(n, 256) < flip_p
+    return np.ascontiguousarray(desc[pick] ^ np.packbits(flips, axis=1, bitorder="little"))
+
+
+def depth_image(seed, h, w, hole_p=0.1):
+    """16U depth plane: smooth surface 0.5..6 m at DepthScale 10 (65535 = 10 m) with zero-valued holes"""
+    rng = Rng(seed)
+    base = 0.5 + 5.5 * (0.5 + 0.5 * _value_noise(rng, h, w, 64, 1.0))
+    d = np.clip(base / 10.0 * 65535.0, 0, 65535).astype(np.uint16)
+    holes = _value_noise(rng, h, w, 16, 1.0) > (1.0 - 2.0 * hole_p) * 0.6
+    d[holes] = 0
+    return np.ascontiguousarray(d)      # the noise planes come out of fancy indexing in Fortran order

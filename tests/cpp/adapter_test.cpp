@@ -8,6 +8,7 @@
 #include <string>
 #include "ssvio/Feature.h"
 #include "ssvio/FeatureMatching.h"
+#include "ssvio/FrameOps.h"
 
 struct Config {                                   // stands in for SSVIO's Config (include/Config.h:26-30)
     typedef std::shared_ptr<Config> Ptr;
@@ -19,7 +20,7 @@ static bool dump(const char* path, const void* p, size_t n) { FILE* f = fopen(pa
 
 int main(int argc, char** argv)
 {
-    if (argc < 6) { fprintf(stderr, "usage: %s frames.raw width height nfeatures outprefix\n", argv[0]); return 2; }
+    if (argc < 6) { fprintf(stderr, "usage: %s frames.raw width height nfeatures outprefix [voc.txt depth.raw]\n", argv[0]); return 2; }
     const int w = atoi(argv[2]), h = atoi(argv[3]), nf = atoi(argv[4]);
     std::string out = argv[5];
     std::vector<unsigned char> raw((size_t)2 * w * h);
@@ -58,6 +59,42 @@ int main(int argc, char** argv)
         std::vector<cv::DMatch> m4;
         fm->MatchByProject(p3, da, p2, db, radian, K, R, t, m4);
         if (fm->lastStatus() != SSVIO_OK) { fprintf(stderr, "MatchByProject: %s\n", ssvio_last_error()); return 1; }
+        if (argc >= 8) {
+            // the live path of Odometry (src/Odometry.cpp:145-176, :205): MatchByDBoW on a vocabulary read from a text file,
+            // then the correspondence lists, then the match chaining of Map
+            FeatureMatching::Ptr fd = std::make_shared<FeatureMatching>(argv[6], cfg);
+            if (!fd->HasVocabulary()) { fprintf(stderr, "vocabulary not loaded\n"); return 1; }
+            std::vector<cv::DMatch> bow; bow.resize(2);
+            const bool okb = fd->MatchByDBoW(db, da, bow);
+            if (fd->lastStatus() != SSVIO_OK || okb != !bow.empty()) { fprintf(stderr, "MatchByDBoW: %s\n", ssvio_last_error()); return 1; }
+            std::vector<cv::DMatch> untouched(2); cv::Mat none;
+            if (fd->MatchByDBoW(none, da, untouched) || untouched.size() != 2) { fprintf(stderr, "MatchByDBoW early return must not clear\n"); return 1; }
+            std::vector<uint16_t> dep((size_t)2 * w * h);
+            FILE* g = fopen(argv[7], "rb");
+            if (!g || fread(dep.data(), 2, dep.size(), g) != dep.size()) { fprintf(stderr, "cannot read depth\n"); return 2; }
+            fclose(g);
+            cv::Mat depA(h, w, CV_16UC1, dep.data(), (size_t)w * 2), depB(h, w, CV_16UC1, dep.data() + (size_t)w * h, (size_t)w * 2);
+            const ssvio_camera cam = ssvio::MakeCamera(160.5912f, 120.4792f, 253.0589f, 254.1649f, 10.0f);
+            ssvio::Correspondences c;
+            if (!ssvio::AssembleCorrespondences(*fd, bow, ka, depA, kb, depB, cam, c)) { fprintf(stderr, "assemble: %s\n", ssvio_last_error()); return 1; }
+            std::vector<cv::DMatch> last = m;                         // stands in for last_match_vec
+            if (!ssvio::TrackMapPoints(*fd, last, c.final_good_match)) { fprintf(stderr, "track: %s\n", ssvio_last_error()); return 1; }
+            std::vector<int> inm;
+            if (!ssvio::InMatchVec(*fd, m, (int)kb.size(), inm)) { fprintf(stderr, "inmatch: %s\n", ssvio_last_error()); return 1; }
+            std::vector<unsigned> fvflat;                             // mFeatVec1_ flattened: node, count, indices...
+            for (auto& e : fd->mFeatVec1_) { fvflat.push_back(e.first); fvflat.push_back((unsigned)e.second.size()); fvflat.insert(fvflat.end(), e.second.begin(), e.second.end()); }
+            std::vector<double> bvflat;
+            for (auto& e : fd->mBowVec1_) { bvflat.push_back((double)e.first); bvflat.push_back(e.second); }
+            dump((out + ".bow").c_str(), bow.data(), bow.size() * sizeof(cv::DMatch));
+            dump((out + ".fv1").c_str(), fvflat.data(), fvflat.size() * 4);
+            dump((out + ".bv1").c_str(), bvflat.data(), bvflat.size() * 8);
+            dump((out + ".l3").c_str(), c.last_frame_3d_point_set.data(), c.last_frame_3d_point_set.size() * 12);
+            dump((out + ".c2").c_str(), c.cur_frame_2d_point_set.data(), c.cur_frame_2d_point_set.size() * 8);
+            dump((out + ".fin").c_str(), c.final_good_match.data(), c.final_good_match.size() * sizeof(cv::DMatch));
+            dump((out + ".trk").c_str(), last.data(), last.size() * sizeof(cv::DMatch));
+            dump((out + ".inm").c_str(), inm.data(), inm.size() * 4);
+            printf("bow=%zu pre=%zu final=%zu track=%zu\n", bow.size(), c.pre_good_match.size(), c.final_good_match.size(), last.size());
+        }
         dump((out + ".p3").c_str(), p3.data(), p3.size() * sizeof(cv::Point3d));
         dump((out + ".m4").c_str(), m4.data(), m4.size() * sizeof(cv::DMatch));
         dump((out + ".ka").c_str(), ka.data(), ka.size() * sizeof(cv::KeyPoint));

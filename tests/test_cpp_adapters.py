@@ -23,7 +23,14 @@ def test_adapters_match_oracle(tmp_path):
     raw = tmp_path / "frames.raw"
     raw.write_bytes(a.tobytes() + b.tobytes())
     out = str(tmp_path / "o")
-    r = subprocess.run([EXE, str(raw), "320", "240", "1200", out], capture_output=True, text=True, timeout=120)
+    from ssvio_amd.vocabulary import Vocabulary
+    par, vdesc, vw = synth.vocabulary_tables(9, 10, 5, stop_p=0.02)
+    voc = Vocabulary(10, 5, par, vdesc, vw)
+    voc.save_txt(str(tmp_path / "voc.txt"))
+    depth = np.stack([synth.depth_image(5, 240, 320), synth.depth_image(6, 240, 320)])
+    (tmp_path / "depth.raw").write_bytes(depth.tobytes())
+    r = subprocess.run([EXE, str(raw), "320", "240", "1200", out, str(tmp_path / "voc.txt"), str(tmp_path / "depth.raw")],
+                       capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "pyr0=320x240" in r.stdout
     ex = O.Extractor(1200, 1.2, 8, 20, 7)
@@ -39,3 +46,21 @@ def test_adapters_match_oracle(tmp_path):
     p2 = np.stack([kb["x"].astype(np.float64), kb["y"].astype(np.float64)], 1)
     want = O.match_project(p3, da, p2, db, 12.0, K, R, t, 50, 0.6)
     assert rd(".m4") == want.tobytes() and len(want) > 10
+    # the live path: MatchByDBoW on the text vocabulary, correspondence lists, match chaining
+    ov = O.Vocabulary(10, 5, par, vdesc, vw, voc.word)
+    bow = O.match_dbow(ov, db, da, 50, 0.6, 4)
+    assert rd(".bow") == bow.tobytes() and len(bow) > 10
+    word, node, weight = ov.transform(db, 4)
+    fv = Vocabulary.feature_vector(node, weight)
+    flat = []
+    for nid, idx in fv.items():
+        flat += [nid, len(idx)] + idx
+    assert rd(".fv1") == np.array(flat, np.uint32).tobytes()
+    bw, bv = ov.bow_vector(word, weight)
+    assert rd(".bv1") == np.stack([bw.astype(np.float64), bv], 1).tobytes()
+    cam = O.camera(160.5912, 120.4792, 253.0589, 254.1649, 10.0)
+    c = O.assemble_correspondences(bow, ka, depth[0], kb, depth[1], cam)
+    assert rd(".l3") == c["last3d"].tobytes() and rd(".c2") == c["cur2d"].tobytes() and rd(".fin") == c["final_good"].tobytes()
+    bf = O.match_bruteforce(db, da)
+    assert rd(".trk") == O.track_map_points(bf, c["final_good"]).tobytes()
+    assert rd(".inm") == O.in_match_vec(bf, len(kb)).tobytes()
