@@ -74,6 +74,10 @@ def algorithmic_bytes(kernel, B, px, nkp_total, pairs_rows):
         return sum(32 * (nq + nt) + 16 * nq for nq, nt in pairs_rows)
     if kernel == "k_match_finalize":
         return sum(8 * nq + 16 * nq for nq, nt in pairs_rows)
+    if kernel == "k_bow_transform":
+        return nkp_total * (32 + 6 * 10 * 32 + 20)     # descriptor + 6 levels x 10 child descriptors read, word/node/weight written
+    if kernel == "k_match_grouped":
+        return sum(36 * (nq + nt) + 24 * nq for nq, nt in pairs_rows)
     return 0
 
 
@@ -88,7 +92,8 @@ def cpu_baseline(frames, nfeatures, match_mode="bf", budget_s=12.0):
         f = frames[n % len(frames)]
         k, d = ex.extract(f)
         if prev is not None:
-            {"bf": O.match_bruteforce, "ratio": O.match_knn2_ratio, "crosscheck": O.match_crosscheck}[match_mode](d, prev)
+            {"bf": O.match_bruteforce, "ratio": O.match_knn2_ratio, "crosscheck": O.match_crosscheck,
+             "dbow": O.match_knn2_ratio}[match_mode](d, prev)      # dbow: the CPU leg times the all-rows 2-NN loop (no 1.1 M-node tree on the host side)
         prev = d
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= 8 * len(frames):
@@ -202,6 +207,39 @@ def batched_matching(rank, world, dev, dist, iters=10):
     return out
 
 
+def next_rows(ex, fm, d_frames, B, W, H, pairs, dev, iters=20):
+    """SURVEY.md §8 "next" rows on the bench's own batch, device-resident: MatchByDBoW (f1) on a synthetic vocabulary of
+    ORBvoc's shape, the correspondence lists of Odometry::OptimizeTransform (f2) and the per-pixel cloud (f4, first half).
+    Per-kernel GPU time from hipEvent pairs, one step in flight; outside the frames/s timed region."""
+    from ssvio_amd import synth
+    depth = np.stack([synth.depth_image(300 + (f % 8), H, W) for f in range(B)])
+    d_depth = torch.from_numpy(np.ascontiguousarray(depth)).to(dev)
+    cam = np.array([W / 2 + 0.59, H / 2 + 0.48, 0.79 * W, 0.79 * W, np.float32(10.0 / 65535.0)], np.float32)
+    fm.set_profiling(True)
+    for _ in range(iters):
+        ex.extract_batch_dev(d_frames, B, W, H, wait=False)
+        d_kp, d_desc, d_n, cap = ex.device_results()
+        dm, dn = fm.match_dbow_batch_dev(d_desc, cap, cap, d_n, B, pairs)
+        fm.assemble_batch_dev(dm, dn, cap, pairs, d_kp, cap, d_n, d_depth, H * W, W, H, W, cam)
+    fm.sync(); ex.sync()
+    t = fm.kernel_times()
+    fm.set_profiling(False)
+    _, nm = fm.fetch_batch(counts_only=True)
+    bgr = synth.to_rgb(synth.texture(5, H, W), 1)
+    fm.set_profiling(True)
+    for _ in range(iters):
+        fm.RGBCloud(depth[0], bgr, cam, 10.0)
+    t.update(fm.kernel_times())
+    fm.set_profiling(False)
+    us = lambda k: round(t[k][0] * 1e3 / max(t[k][1], 1), 2) if k in t else None
+    return {"workload": "%d frames of %dx%d: MatchByDBoW frame f vs f-1 (vocabulary k=10, L=6, 1111111 nodes, levelsup 4), correspondence "
+                        "assembly on its matches, one %dx%d cloud" % (B, W, H, W, H),
+            "avg_us_per_launch": {k: us(k) for k in ("k_bow_transform", "k_match_grouped", "k_assemble", "k_rgb_cloud")},
+            "launch_covers": {"k_bow_transform": "%d descriptor sets" % B, "k_match_grouped": "%d frame pairs (2 kernels: match + ordered compaction)" % len(pairs),
+                              "k_assemble": "%d frame pairs" % len(pairs), "k_rgb_cloud": "one frame, %d points" % (W * H)},
+            "dbow_matches_per_frame": round(float(nm.mean()), 1)}
+
+
 def trace(msg):
     if os.environ.get("SSVIO_BENCH_TRACE"):
         print("[bench rank %s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
@@ -216,8 +254,10 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--features", type=int, default=1000)
-    ap.add_argument("--match-mode", choices=["bf", "ratio", "crosscheck"], default="bf",
-                    help="bf = MatchByBruteForce (config 2); ratio = kNN2 + Threshold/NNRatio (config 3)")
+    ap.add_argument("--match-mode", choices=["bf", "ratio", "crosscheck", "dbow"], default="bf",
+                    help="bf = MatchByBruteForce (config 2); ratio = kNN2 + Threshold/NNRatio (config 3); "
+                         "dbow = MatchByDBoW on a synthetic k=10, L=6 vocabulary (what Odometry calls, src/Odometry.cpp:169)")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8-f section (MatchByDBoW, correspondence assembly, cloud)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched-matching", action="store_true", help="skip the configs[3]/[4] matching section")
     ap.add_argument("--sync-steps", action="store_true", help="host waits for every step (latency mode)")
@@ -263,7 +303,13 @@ def main():
     # stream and the host does not wait inside a step; --sync-steps restores one host wait per step
     for e, m in zip(exs, fms):
         m.set_stream(e.get_stream())
-    mode = {"bf": L.MODE_BRUTEFORCE, "ratio": L.MODE_KNN2_RATIO, "crosscheck": L.MODE_CROSSCHECK}[args.match_mode]
+    mode = {"bf": L.MODE_BRUTEFORCE, "ratio": L.MODE_KNN2_RATIO, "crosscheck": L.MODE_CROSSCHECK, "dbow": -1}[args.match_mode]
+    voc = None
+    if args.match_mode == "dbow" or not args.no_next_rows:
+        par, vdesc, vw = synth.vocabulary_tables_full(7, 10, 6)           # ORBvoc's shape: k = 10, L = 6, 1 111 111 nodes
+        voc = ssvio_amd.Vocabulary(10, 6, par, vdesc, vw)
+        for m in fms:
+            m.mVoc_ = voc
     nstep = [0]
     inflight = [S]
 
@@ -272,7 +318,10 @@ def main():
         nstep[0] += 1
         e.extract_batch_dev(d_frames, B, W, H, wait=args.sync_steps)
         d_kp, d_desc, d_n, cap = e.device_results()
-        m.match_batch_dev(d_desc, cap, cap, d_n, pairs, mode)
+        if mode < 0:
+            m.match_dbow_batch_dev(d_desc, cap, cap, d_n, B, pairs)
+        else:
+            m.match_batch_dev(d_desc, cap, cap, d_n, pairs, mode)
         if args.sync_steps:
             m.sync()
 
@@ -377,6 +426,7 @@ def main():
         valu = None
 
     trace('kernel table done')
+    nxt = None if args.no_next_rows else next_rows(exs[0], fms[0], d_frames, B, W, H, pairs, dev)
     bm = None if args.no_batched_matching else batched_matching(rank, world, dev, dist)
     if rank == 0:
         out = {
@@ -387,7 +437,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %dx%d stream, %d features/frame, 8 levels, extract + %s vs previous frame"
                                    % ("configs[1]" if (W, H, args.features, args.match_mode) == (640, 480, 1000, "bf") else "configs[2]" if (W, H, args.features, args.match_mode) == (1920, 1080, 4000, "ratio") else "custom",
-                                      W, H, args.features, {"bf": "MatchByBruteForce", "ratio": "kNN2 ratio test", "crosscheck": "cross-check"}[args.match_mode]),
+                                      W, H, args.features, {"bf": "MatchByBruteForce", "ratio": "kNN2 ratio test", "crosscheck": "cross-check", "dbow": "MatchByDBoW (synthetic k=10 L=6 vocabulary)"}[args.match_mode]),
                        "frames_per_step": B, "parallelism": "frames sharded over %d rank(s), replicas, no collective on the data path" % world,
                        "steps_in_flight": S},
             "keypoints_per_frame": round(float(counts.mean()), 1),
@@ -398,6 +448,7 @@ def main():
                               "kernels": "second pass of the same steps, one step in flight, pairs around every kernel (exclusive times)"},
             "host_waits": "per step" if args.sync_steps else "none inside the timed region (pipelined)",
             "batched_matching": bm,
+            "next_rows": nxt,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, args.features, args.match_mode)

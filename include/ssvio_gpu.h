@@ -275,6 +275,15 @@ int  ssvio_track_map_points(ssvio_matcher* m, const ssvio_dmatch* last, int nlas
  * out[i] = index of the first match with queryIdx == i, or -1 */
 int  ssvio_in_match_vec(ssvio_matcher* m, const ssvio_dmatch* vec, int n, int nkp, int32_t* out);
 
+/* ---- per-pixel cloud (first half) ---------------------------------------------------------- */
+/* The cloud loop of XtionCamera::GrabImage, driver/Xtion_Driver.cpp:219-229, over GetRGB3DPoint (:138-162): one
+ * pcl::PointXYZRGB (32 bytes: x, y, z, 1.0f, b, g, r, a = 255, 12 bytes of padding written as 0) per pixel, point index
+ * u * h + v for pixel (x = u, y = v).  depth: 16U w x h; bgr: 8UC3 with bytes B, G, R (:215).  depth_scale is the driver's
+ * DOUBLE _DepthScale (driver/Xtion_Driver.h:47: (float)yaml DepthScale / 65535.0), cam->depth_scale is not used.
+ * out: w*h records.  (The voxel-grid fusion of Map::MapPointCloudFusion is PCL code and is not built.) */
+int  ssvio_rgb_cloud(ssvio_matcher* m, const uint16_t* depth, int depth_stride_px, const uint8_t* bgr, int bgr_stride,
+                     int w, int h, const ssvio_camera* cam, double depth_scale, void* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,8 @@
  *   src/Odometry.cpp:94-108     ICP edge list / _final_good_match      -> orc_assemble_correspondences, second list
  *   src/Map.cpp:100-123         Map::TrackMapPoints                    -> orc_track_map_points
  *   src/Map.cpp:151-162         Map::InMatchVec (for every keypoint)   -> orc_in_match_vec
- * (SURVEY.md §8 rows f2, f3.)  All float arithmetic is single precision, evaluated left to right, no contraction.
+ *   driver/Xtion_Driver.cpp:138-162, :219-229  XtionCamera::GetRGB3DPoint over the frame -> orc_rgb_cloud (f4, first half)
+ * (SURVEY.md §8 rows f2, f3, f4.)  All float arithmetic is single precision, evaluated left to right, no contraction.
  */
 #include "ssvio_oracle.h"
 #include <float.h>
@@ -82,5 +83,30 @@ void orc_in_match_vec(const orc_dmatch* vec, int n, int nkp, int32_t* out)
     for (int i = 0; i < nkp; ++i) {
         out[i] = -1;
         for (int j = 0; j < n; ++j) if (vec[j].queryIdx == i) { out[i] = j; break; }
+    }
+}
+
+/* XtionCamera::GrabImage's cloud loop (driver/Xtion_Driver.cpp:219-229) over GetRGB3DPoint (:138-162): point
+ * i = u * rows + v (column-major) from pixel (x = u, y = v).  The driver's _DepthScale is a DOUBLE
+ * (driver/Xtion_Driver.h:47, = (float)yaml / 65535.0 in double, .cpp:14): the product with the raw depth is formed in
+ * double and narrowed once.  bgr: 8UC3 image whose bytes are B, G, R (the driver converted, :215).
+ * out: pcl::PointXYZRGB records of 32 bytes {x, y, z, 1.0f, b, g, r, a = 255, 12 bytes 0}. */
+void orc_rgb_cloud(const uint16_t* depth, int depth_stride_px, const uint8_t* bgr, int bgr_stride, int w, int h,
+                   float cx, float cy, float fx, float fy, double depth_scale, uint8_t* out)
+{
+    const float inv_fx = 1 / fx, inv_fy = 1 / fy;                      /* .cpp:15-16 */
+    for (int u = 0; u < w; ++u) {
+        for (int v = 0; v < h; ++v) {
+            const float d = (float)((double)depth[(size_t)v * depth_stride_px + u] * depth_scale);    /* :146 */
+            float p[4];
+            p[0] = ((float)u - cx) * d * inv_fx;                        /* :149 */
+            p[1] = ((float)v - cy) * d * inv_fy;
+            p[2] = d; p[3] = 1.0f;
+            uint8_t* o = out + ((size_t)u * h + v) * 32;
+            for (int k = 0; k < 16; ++k) o[k] = ((const uint8_t*)p)[k];
+            const uint8_t* c = bgr + (size_t)v * bgr_stride + 3 * u;
+            o[16] = c[0]; o[17] = c[1]; o[18] = c[2]; o[19] = 255;       /* :157-159; a = 255 is PointXYZRGB's default */
+            for (int k = 20; k < 32; ++k) o[k] = 0;
+        }
     }
 }

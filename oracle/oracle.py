@@ -84,6 +84,7 @@ def lib():
         L.orc_assemble_correspondences.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp] + [vp] * 9
         L.orc_track_map_points.restype = i32; L.orc_track_map_points.argtypes = [vp, i32, vp, i32, vp]
         L.orc_in_match_vec.argtypes = [vp, i32, i32, vp]
+        L.orc_rgb_cloud.argtypes = [vp, i32, vp, i32, i32, i32, f32, f32, f32, f32, C.c_double, vp]
         _lib = L
     return _lib
 
@@ -416,4 +417,17 @@ def in_match_vec(vec, nkp):
     vec = np.ascontiguousarray(vec, DM_DTYPE)
     out = np.zeros(nkp, np.int32)
     lib().orc_in_match_vec(_p(vec), len(vec), nkp, _p(out))
+    return out
+
+
+CLOUD_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"), ("a", "u1"),
+                        ("pad", "u1", 12)])        # pcl::PointXYZRGB, 32 bytes
+
+
+def rgb_cloud(depth, bgr, cx, cy, fx, fy, depth_scale_yaml):
+    """driver/Xtion_Driver.cpp:219-229: w*h points, index u*rows + v"""
+    depth = np.ascontiguousarray(depth, np.uint16); bgr = _u8(bgr)
+    h, w = depth.shape
+    out = np.zeros(w * h, CLOUD_DTYPE)
+    lib().orc_rgb_cloud(_p(depth), w, _p(bgr), bgr.strides[0], w, h, cx, cy, fx, fy, float(np.float32(depth_scale_yaml)) / 65535.0, _p(out))
     return out

@@ -19,6 +19,10 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 DM_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])  # cv::DMatch
 
 
+CLOUD_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"), ("a", "u1"),
+                        ("pad", "u1", 12)])        # pcl::PointXYZRGB, 32 bytes
+
+
 class OrbParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
@@ -90,6 +94,7 @@ SYMBOLS = {
     "ssvio_assemble_batch_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _vp, _vp]),
     "ssvio_track_map_points": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "ssvio_in_match_vec": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ssvio_rgb_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, C.c_double, _vp]),
 }
 
 _lib = None

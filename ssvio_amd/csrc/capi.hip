@@ -768,6 +768,7 @@ struct ssvio_matcher {
     int32_t* d_bowWord = nullptr; size_t bowWordCap = 0; int32_t* d_bowNode = nullptr; size_t bowNodeCap = 0;
     double* d_bowWeight = nullptr; size_t bowWeightCap = 0; int32_t* d_gnode = nullptr; size_t gnodeCap = 0;
     int32_t* d_keepNode = nullptr; size_t keepNodeCap = 0;
+    int32_t* d_sortIdx = nullptr; size_t sortIdxCap = 0; int32_t* d_sortNode = nullptr; size_t sortNodeCap = 0;
     int lastBowQ = 0, lastBowT = 0;
     // behind the matcher (f2, f3)
     uint8_t* d_frameIn = nullptr; size_t frameInCap = 0;      // uploaded matches / keypoints / depth of the host entry points
@@ -948,7 +949,7 @@ void ssvio_matcher_destroy(ssvio_matcher* m)
     dfree(m->d_q); dfree(m->d_t); dfree(m->d_counts2); dfree(m->d_partial); dfree(m->d_partialRev);
     dfree(m->d_out); dfree(m->d_raw); dfree(m->d_nout); dfree(m->d_pairs);
     dfree(m->d_p3d); dfree(m->d_p2d); dfree(m->d_cand); dfree(m->d_keep);
-    dfree(m->d_bowWord); dfree(m->d_bowNode); dfree(m->d_bowWeight); dfree(m->d_gnode); dfree(m->d_keepNode);
+    dfree(m->d_bowWord); dfree(m->d_bowNode); dfree(m->d_bowWeight); dfree(m->d_gnode); dfree(m->d_keepNode); dfree(m->d_sortIdx); dfree(m->d_sortNode);
     dfree(m->d_frameIn); dfree(m->d_frameOut); dfree(m->d_table);
     if (m->own) (void)hipStreamDestroy(m->own);
     delete m;
@@ -1124,7 +1125,19 @@ static int bow_grow(ssvio_matcher* m, size_t rows)
     int rc = grow(m->d_bowWord, m->bowWordCap, rows, s); if (rc) return rc;
     rc = grow(m->d_bowNode, m->bowNodeCap, rows, s); if (rc) return rc;
     rc = grow(m->d_bowWeight, m->bowWeightCap, rows, s); if (rc) return rc;
+    rc = grow(m->d_sortIdx, m->sortIdxCap, rows, s); if (rc) return rc;
+    rc = grow(m->d_sortNode, m->sortNodeCap, rows, s); if (rc) return rc;
     return grow(m->d_gnode, m->gnodeCap, rows, s);
+}
+
+// order the rows of `nsets` transformed sets by (node id, index); same row indexing as bow_run
+static void bow_sort(ssvio_matcher* m, int setStrideRows, const int* d_counts, int nsets, size_t rowBase)
+{
+    BowSortArgs a{};
+    a.gnode = m->d_gnode + rowBase; a.setStrideRows = setStrideRows; a.counts = d_counts;
+    a.sortedIdx = m->d_sortIdx + rowBase; a.sortedNode = m->d_sortNode + rowBase;
+    ProfScope p(m->prof, "k_bow_sort", m->stream);
+    launch_bow_sort(a, nsets, m->stream);
 }
 
 // transform the rows of `nsets` descriptor sets; per-feature results land at rowBase + set * setStrideRows + i
@@ -1251,12 +1264,23 @@ int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, i
     SSVIO_HIP(hipStreamSynchronize(s));
     bow_run(m, v, m->d_q, 0, m->d_counts2, 1, nq, levelsup, 0);               // ComputeBoWVector(desp1), :68
     bow_run(m, v, m->d_t, 0, m->d_counts2 + 1, 1, nt, levelsup, (size_t)nq);  // ComputeBoWVector(desp2), :69
-    GroupedArgs g{};
-    g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + nq;
-    g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
-    g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq;
-    g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
-    {
+    if (std::max(nq, nt) <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED")) {
+        bow_sort(m, 0, m->d_counts2, 1, 0);
+        bow_sort(m, 0, m->d_counts2 + 1, 1, (size_t)nq);
+        SortedMatchArgs g{};
+        g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t;
+        g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx + nq; g.tSortedNode = m->d_sortNode + nq;
+        g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq;
+        g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
+        ProfScope p(m->prof, "k_match_sorted", s);
+        launch_match_sorted(g, nq, nt, 1, s);
+    } else {                                                           // sets beyond the LDS sort: wave per query over all train rows
+        GroupedArgs g{};
+        g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + nq;
+        g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq;
+        g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
         ProfScope p(m->prof, "k_match_grouped", s);
         launch_match_grouped(g, nq, 1, s);
     }
@@ -1305,12 +1329,22 @@ int ssvio_match_dbow_batch_dev(ssvio_matcher* m, const ssvio_vocab* v, const voi
     rc = grow(m->d_out, m->outCap, (size_t)npairs * max_rows, s); if (rc) return rc;
     rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
     bow_run(m, v, (const uint8_t*)d_desc, set_stride_rows, d_counts, nsets, max_rows, levelsup, 0);   // once per set, not per pair
-    GroupedArgs g{};
-    g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode;
-    g.qSetStrideRows = set_stride_rows; g.tSetStrideRows = set_stride_rows; g.qcounts = d_counts; g.tcounts = d_counts; g.pairs = m->d_pairs;
-    g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows;
-    g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
-    {
+    if (max_rows <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED")) {
+        bow_sort(m, set_stride_rows, d_counts, nsets, 0);
+        SortedMatchArgs g{};
+        g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc;
+        g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx; g.tSortedNode = m->d_sortNode;
+        g.qSetStrideRows = set_stride_rows; g.tSetStrideRows = set_stride_rows; g.qcounts = d_counts; g.tcounts = d_counts; g.pairs = m->d_pairs;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows;
+        g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
+        ProfScope p(m->prof, "k_match_sorted", s);
+        launch_match_sorted(g, max_rows, max_rows, npairs, s);
+    } else {
+        GroupedArgs g{};
+        g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode;
+        g.qSetStrideRows = set_stride_rows; g.tSetStrideRows = set_stride_rows; g.qcounts = d_counts; g.tcounts = d_counts; g.pairs = m->d_pairs;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows;
+        g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
         ProfScope p(m->prof, "k_match_grouped", s);
         launch_match_grouped(g, max_rows, npairs, s);
     }
@@ -1530,3 +1564,28 @@ int ssvio_in_match_vec(ssvio_matcher* m, const ssvio_dmatch* vec, int n, int nkp
 }
 
 }  // extern "C"
+
+extern "C" int ssvio_rgb_cloud(ssvio_matcher* m, const uint16_t* depth, int depth_stride_px, const uint8_t* bgr, int bgr_stride,
+                               int w, int h, const ssvio_camera* cam, double depth_scale, void* out)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    FrameCam c; int rc = cam_dev(cam, w, h, depth_stride_px, c); if (rc) return rc;
+    if (!depth || !bgr || !out || bgr_stride < 3 * w) { set_error("bad cloud arguments"); return SSVIO_ERR_INVALID; }
+    if ((size_t)w * h > ((size_t)1 << 28)) { set_error("image too large"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t db = align256((size_t)h * depth_stride_px * 2), cb = align256((size_t)h * bgr_stride), ob = (size_t)w * h * 32;
+    rc = grow(m->d_frameIn, m->frameInCap, db + cb, s); if (rc) return rc;
+    rc = grow(m->d_frameOut, m->frameOutCap, ob, s); if (rc) return rc;
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, depth, (size_t)h * depth_stride_px * 2, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn + db, bgr, (size_t)h * bgr_stride, hipMemcpyHostToDevice, s));
+    {
+        ProfScope p(m->prof, "k_rgb_cloud", s);
+        launch_rgb_cloud((const uint16_t*)m->d_frameIn, depth_stride_px, m->d_frameIn + db, bgr_stride, w, h, c.cx, c.cy, c.invFx, c.invFy,
+                         depth_scale, m->d_frameOut, s);
+    }
+    SSVIO_HIP(hipMemcpyAsync(out, m->d_frameOut, ob, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    m->prof.resolve();
+    return SSVIO_OK;
+}

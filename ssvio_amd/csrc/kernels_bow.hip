@@ -119,4 +119,112 @@ void launch_match_grouped(const GroupedArgs& a, int maxQ, int npairs, hipStream_
     hipLaunchKernelGGL(k_grouped_compact, dim3((maxQ + 255) / 256, npairs), dim3(256), 0, s, a);
 }
 
+// ---------------------------------------------------------------------------
+// Sorted form.  k_bow_sort: one workgroup per set, bitonic sort of (key << 32 | index) in LDS, so that every vocabulary
+// node's features are one contiguous run in ascending feature index (a FeatureVector entry, laid out flat) and the
+// runs follow each other in ascending node id (the std::map order); stopped words (key -1 = 0xFFFFFFFF) sort last.
+__global__ __launch_bounds__(1024) void k_bow_sort(BowSortArgs a)
+{
+    __shared__ unsigned long long key[kBowSortMax];
+    const int set = blockIdx.x, tid = threadIdx.x;
+    const int n = min(a.counts[set], kBowSortMax);
+    const size_t base = (size_t)set * a.setStrideRows;
+    int P = 1024;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += 1024)
+        key[i] = i < n ? (((unsigned long long)(uint32_t)a.gnode[base + i] << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = key[i], y = key[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { key[i] = y; key[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += 1024) {
+        a.sortedIdx[base + i] = (int32_t)(uint32_t)key[i];
+        a.sortedNode[base + i] = (int32_t)(uint32_t)(key[i] >> 32);
+    }
+}
+
+void launch_bow_sort(const BowSortArgs& a, int nsets, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bow_sort, dim3(nsets), dim3(1024), 0, s, a);
+}
+
+// one thread per query feature, taken in sorted rank order: its node's run in the train set is found by binary search and
+// walked in ascending train index -- literally the loop of src/FeatureMatching.cpp:82-102 over vIdx2.  The train set's
+// sorted keys and indices are staged in LDS once per workgroup (2 x 4 bytes per row, <= 64 KB), so the searches and the
+// run walk stay on chip and only the candidates' descriptors are fetched from HBM / L2.
+__global__ __launch_bounds__(256) void k_match_sorted(SortedMatchArgs a)
+{
+    extern __shared__ int32_t lds[];
+    const int pair = blockIdx.y;
+    const int qset = a.pairs ? a.pairs[2 * pair] : 0, tset = a.pairs ? a.pairs[2 * pair + 1] : 0;
+    const int nq = a.qcounts[qset], nt = min(a.tcounts[tset], kBowSortMax);
+    if ((int)(blockIdx.x * 256) >= nq) return;                          // block-uniform
+    const size_t qb = (size_t)qset * a.qSetStrideRows, tb = (size_t)tset * a.tSetStrideRows;
+    int32_t* sNode = lds; int32_t* sIdx = lds + nt;
+    for (int j = threadIdx.x; j < nt; j += 256) { sNode[j] = a.tSortedNode[tb + j]; sIdx[j] = a.tSortedIdx[tb + j]; }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nq) return;
+    const int node = a.qSortedNode[qb + r], i = a.qSortedIdx[qb + r];
+    int bestDist1 = 256, bestDist2 = 256, bestIdx = -1;                 // :85-87
+    int lo = 0, hi = 0;
+    if (node >= 0) {
+        int l = 0, h = nt;                                              // first rank whose key is >= node (keys compare unsigned)
+        while (l < h) { const int mid = (l + h) >> 1; if ((uint32_t)sNode[mid] < (uint32_t)node) l = mid + 1; else h = mid; }
+        lo = l; h = nt;                                                 // first rank whose key is > node
+        while (l < h) { const int mid = (l + h) >> 1; if ((uint32_t)sNode[mid] <= (uint32_t)node) l = mid + 1; else h = mid; }
+        hi = l;
+    }
+    if (lo < hi) {
+        const uint4 qlo = a.qdesc[2 * (qb + i)], qhi = a.qdesc[2 * (qb + i) + 1];
+#pragma unroll 4
+        for (int p = lo; p < hi; ++p) {
+            const int j = sIdx[p];
+            const int dist = (int)hamming256(qlo, qhi, a.tdesc[2 * (tb + j)], a.tdesc[2 * (tb + j) + 1]);
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx = j; }      // :94-101
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+    }
+    const bool keep = lo < hi && bestDist1 <= a.threshold && (float)bestDist1 < a.nnRatio * (float)bestDist2;   // :104-105
+    ssvio_dmatch m; m.queryIdx = i; m.trainIdx = bestIdx; m.imgIdx = -1; m.distance = (float)bestDist1;
+    const size_t o = (size_t)pair * a.maxRows + r;
+    a.cand[o] = m; a.keep[o] = keep ? 1 : 0;
+}
+
+// kept matches in rank order = ascending (node id, query index), the reference's push_back order
+__global__ __launch_bounds__(256) void k_sorted_compact(SortedMatchArgs a)
+{
+    __shared__ int wsum[4];
+    const int pair = blockIdx.x;
+    const int qset = a.pairs ? a.pairs[2 * pair] : 0, tset = a.pairs ? a.pairs[2 * pair + 1] : 0;
+    const int nq = a.tcounts[tset] > 0 ? a.qcounts[qset] : 0;           // :61-63: nothing with an empty train set
+    const size_t ob = (size_t)pair * a.maxRows;
+    int written = 0;
+    for (int r0 = 0; r0 < nq; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        const bool keep = r < nq && a.keep[ob + r];
+        int total;
+        const int off = block_excl_scan(keep ? 1 : 0, wsum, total);
+        if (keep) a.out[ob + written + off] = a.cand[ob + r];
+        written += total;
+    }
+    if (threadIdx.x == 0) a.nout[pair] = written;
+}
+
+void launch_match_sorted(const SortedMatchArgs& a, int maxQ, int maxT, int npairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_match_sorted, dim3((maxQ + 255) / 256, npairs), dim3(256), (size_t)min(maxT, kBowSortMax) * 8, s, a);      // LDS: keys + indices of the largest train set
+    hipLaunchKernelGGL(k_sorted_compact, dim3(npairs), dim3(256), 0, s, a);
+}
+
 }  // namespace ssvio

@@ -6,6 +6,7 @@
 //   k_first_index     index map "key -> first position in a DMatch list" (atomicMin), which replaces the linear
 //                     searches of Map::InMatchVec (src/Map.cpp:151-162) and Map::TrackMapPoints (:100-123)
 //   k_track           TrackMapPoints' join through that map, emitted in last_match_vec order
+//   k_rgb_cloud       the per-pixel cloud of XtionCamera::GrabImage (driver/Xtion_Driver.cpp:138-162, :219-229; f4, first half)
 // Float code is single precision, left to right, no contraction (this library is built with -ffp-contract=off).
 #include "match.h"
 #include <cfloat>
@@ -36,6 +37,37 @@ __global__ __launch_bounds__(256) void k_get_3d_points(const ssvio_keypoint* kps
 void launch_get_3d_points(const ssvio_keypoint* kps, int n, const uint16_t* depth, const FrameCam& c, float* out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_get_3d_points, dim3((n + 255) / 256), dim3(256), 0, s, kps, n, depth, c, out);
+}
+
+// XtionCamera::GrabImage's cloud loop (driver/Xtion_Driver.cpp:219-229): point u * rows + v from pixel (u, v).  A 16 x 16
+// pixel tile per workgroup: threads read along rows (coalesced depth / colour loads), transpose through LDS and write
+// along columns (16 consecutive 32-byte points per tile column).  depth * _DepthScale is a double product (Xtion_Driver.h:47).
+__global__ __launch_bounds__(256) void k_rgb_cloud(const uint16_t* depth, int depthStridePx, const uint8_t* bgr, int bgrStride,
+                                                   int w, int h, float cx, float cy, float invFx, float invFy, double depthScale, uint4* out)
+{
+    __shared__ uint4 lo[16][17], hi[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int u = blockIdx.x * 16 + tx, v = blockIdx.y * 16 + ty;
+    if (u < w && v < h) {
+        const float d = (float)((double)depth[(size_t)v * depthStridePx + u] * depthScale);          // :146
+        const float x = ((float)u - cx) * d * invFx, y = ((float)v - cy) * d * invFy;                 // :149-150
+        const uint8_t* c = bgr + (size_t)v * bgrStride + 3 * u;
+        lo[ty][tx] = make_uint4(__float_as_uint(x), __float_as_uint(y), __float_as_uint(d), __float_as_uint(1.0f));
+        hi[ty][tx] = make_uint4((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | 0xFF000000u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    const int ou = blockIdx.x * 16 + ty, ov = blockIdx.y * 16 + tx;       // transposed: consecutive threads -> consecutive v
+    if (ou < w && ov < h) {
+        uint4* o = out + 2 * ((size_t)ou * h + ov);
+        o[0] = lo[tx][ty]; o[1] = hi[tx][ty];
+    }
+}
+
+void launch_rgb_cloud(const uint16_t* depth, int depthStridePx, const uint8_t* bgr, int bgrStride, int w, int h,
+                      float cx, float cy, float invFx, float invFy, double depthScale, void* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rgb_cloud, dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, s, depth, depthStridePx, bgr, bgrStride, w, h,
+                       cx, cy, invFx, invFy, depthScale, (uint4*)out);
 }
 
 // one workgroup per frame pair; match i of the pair is handled by thread i % 256 in pass i / 256

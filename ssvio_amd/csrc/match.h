@@ -64,6 +64,23 @@ struct GroupedArgs {
 };
 void launch_match_grouped(const GroupedArgs& a, int maxQ, int npairs, hipStream_t s);
 
+// sorted form (sets of up to kBowSortMax rows): features of a set ordered by (grouping key, index), stopped words last
+constexpr int kBowSortMax = 8192;
+struct BowSortArgs {
+    const int32_t* gnode; int setStrideRows; const int* counts;      // per set: gnode + set * setStrideRows, counts[set] rows
+    int32_t* sortedIdx; int32_t* sortedNode;                         // same indexing: rank r -> feature index / its key
+};
+void launch_bow_sort(const BowSortArgs& a, int nsets, hipStream_t s);
+struct SortedMatchArgs {
+    const uint4* qdesc; const uint4* tdesc;
+    const int32_t* qSortedIdx; const int32_t* qSortedNode; const int32_t* tSortedIdx; const int32_t* tSortedNode;
+    int qSetStrideRows, tSetStrideRows; const int* qcounts; const int* tcounts; const int* pairs;
+    int threshold; float nnRatio; int maxRows;
+    ssvio_dmatch* cand; int32_t* keep;         // [pair][maxRows], indexed by the query's rank
+    ssvio_dmatch* out; int* nout;
+};
+void launch_match_sorted(const SortedMatchArgs& a, int maxQ, int maxT, int npairs, hipStream_t s);
+
 // behind the matcher: Frame::Get3DPoint, correspondence assembly, match chaining
 struct FrameCam { float cx, cy, invFx, invFy, depthScale; int w, h, stridePx; };
 struct AssembleArgs {
@@ -78,6 +95,8 @@ struct AssembleArgs {
 };
 void launch_get_3d_points(const ssvio_keypoint* kps, int n, const uint16_t* depth, const FrameCam& c, float* out, hipStream_t s);
 void launch_assemble(const AssembleArgs& a, int npairs, hipStream_t s);
+void launch_rgb_cloud(const uint16_t* depth, int depthStridePx, const uint8_t* bgr, int bgrStride, int w, int h,
+                      float cx, float cy, float invFx, float invFy, double depthScale, void* out, hipStream_t s);
 void launch_first_index(const ssvio_dmatch* v, int n, int useTrain, uint32_t* table, int tableSize, hipStream_t s);
 void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, const uint32_t* table, int tableSize,
                   ssvio_dmatch* out, int* nout, hipStream_t s);

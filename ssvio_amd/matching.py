@@ -154,6 +154,17 @@ class FeatureMatching:
                                                  w, h, stride_px, L.ptr(c), C.byref(out)))
         return out
 
+    def RGBCloud(self, depth, bgr, cam, depth_scale_yaml):
+        """the cloud loop of XtionCamera::GrabImage (driver/Xtion_Driver.cpp:219-229): w*h pcl::PointXYZRGB records, index u*h + v"""
+        depth = np.ascontiguousarray(depth, np.uint16); bgr = np.ascontiguousarray(bgr, np.uint8); c = self._cam(cam)
+        h, w = depth.shape
+        if bgr.shape != (h, w, 3):
+            raise ValueError("bgr must be h x w x 3")
+        out = np.zeros(w * h, L.CLOUD_DTYPE)
+        L.check(L.lib().ssvio_rgb_cloud(self._h, L.ptr(depth), w, L.ptr(bgr), bgr.strides[0], w, h, L.ptr(c),
+                                        float(np.float32(depth_scale_yaml)) / 65535.0, L.ptr(out)))
+        return out
+
     def TrackMapPoints(self, last_match_vec, this_match_vec):
         """Map::TrackMapPoints (src/Map.cpp:100-123) -> the new last_match_vec"""
         last = np.ascontiguousarray(last_match_vec, L.DM_DTYPE); cur = np.ascontiguousarray(this_match_vec, L.DM_DTYPE)

@@ -177,6 +177,27 @@ def vocabulary_tables(seed, k=10, L=3, flip0=0.30, early_leaf_p=0.0, stop_p=0.05
     return par, np.array(desc, np.uint8), w
 
 
+def vocabulary_tables_full(seed, k=10, L=6):
+    """complete k-ary tree of depth L built level by level with array operations (ORBvoc's shape, k = 10, L = 6, is
+    1 111 111 nodes): a child flips each parent bit with probability 2^-(level + 2) (AND of random bit planes).
+    Breadth-first ids (parent[n] < n, children of a node contiguous and ascending).  Returns parent, desc, weight."""
+    rng = Rng(seed)
+    parents = [np.array([-1], np.int32)]; descs = [rng.bytes(32).reshape(1, 32)]
+    first = 0
+    for level in range(L):
+        cur = descs[-1]; n = len(cur)
+        flips = rng.bytes(n * k * 32).reshape(n * k, 32)
+        for _ in range(level + 1):
+            flips &= rng.bytes(n * k * 32).reshape(n * k, 32)
+        descs.append(np.repeat(cur, k, axis=0) ^ flips)
+        parents.append(np.repeat(np.arange(first, first + n, dtype=np.int32), k))
+        first += n
+    parent = np.concatenate(parents); desc = np.ascontiguousarray(np.concatenate(descs))
+    w = 0.5 + 4.0 * rng.uniform(len(parent))
+    w[rng.uniform(len(parent)) < 0.01] = 0.0
+    return parent, desc, w
+
+
 def descriptors_near_leaves(seed, n, parent, desc, flip_p=0.03):
     """n descriptors: random leaves of the tree with bits flipped w.p. flip_p"""
     rng = Rng(seed)

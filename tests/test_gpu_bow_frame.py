@@ -272,3 +272,34 @@ def test_track_map_points_and_in_match_vec_equal_oracle(mods, seed, nlast, ncur,
     assert len(fm.TrackMapPoints(last[:0], cur)) == 0 and len(fm.TrackMapPoints(last, cur[:0])) == 0
     assert np.array_equal(fm.InMatchVec(last[:0], 7), np.full(7, -1, np.int32))
     fm.close()
+
+
+@pytest.mark.parametrize("h,w", [(240, 320), (480, 640), (37, 53), (1, 1)])
+def test_rgb_cloud_equals_oracle(mods, h, w):
+    S, synth, O, V, L = mods
+    depth = synth.depth_image(91, h, w) if h > 8 else np.array([[4711]], np.uint16)
+    bgr = synth.to_rgb(synth.texture(92, max(h, 16), max(w, 16))[:h, :w], 3)
+    cam = O.camera(160.5912, 120.4792, 253.0589, 254.1649, 10.0)
+    fm = S.FeatureMatching(None, {})
+    got = fm.RGBCloud(depth, bgr, cam, 10.0)
+    want = O.rgb_cloud(depth, bgr, 160.5912, 120.4792, 253.0589, 254.1649, 10.0)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    fm.close()
+
+
+def test_match_dbow_unsorted_path_and_large_sets(mods, monkeypatch):
+    """sets beyond the LDS sort (> 8192 rows) take the wave-per-query kernels; both paths give the oracle's list"""
+    S, synth, O, V, L = mods
+    v, ov, par, desc = _pair(mods, 17, 10, 3)
+    t = synth.descriptors_near_leaves(18, 8300, par, desc, 0.03)
+    q = t[np.random.default_rng(5).integers(0, 8300, 8200)] ^ np.packbits(np.random.default_rng(6).random((8200, 256)) < 0.02, axis=1, bitorder="little")
+    fm = S.FeatureMatching(v, {"Threshold": 50, "NNRatio": 0.6})
+    want = O.match_dbow(ov, q, t, 50, 0.6, 1)
+    assert len(want) > 1000
+    assert np.array_equal(_bytes(fm.MatchByDBoW(q, t, levelsup=1)[1]), _bytes(want))                     # 8300 rows: unsorted path
+    assert np.array_equal(_bytes(fm.MatchByDBoW(q[:8192], t[:8192], levelsup=1)[1]), _bytes(O.match_dbow(ov, q[:8192], t[:8192], 50, 0.6, 1)))   # sorted, full LDS
+    small = O.match_dbow(ov, q[:900], t[:1000], 50, 0.6, 1)
+    assert np.array_equal(_bytes(fm.MatchByDBoW(q[:900], t[:1000], levelsup=1)[1]), _bytes(small))      # sorted path
+    monkeypatch.setenv("SSVIO_DBOW_UNSORTED", "1")
+    assert np.array_equal(_bytes(fm.MatchByDBoW(q[:900], t[:1000], levelsup=1)[1]), _bytes(small))      # same inputs, unsorted path
+    fm.close(); v.close()

@@ -212,3 +212,21 @@ def test_in_match_vec_first_position(oracle):
     v = np.zeros(5, oracle.DM_DTYPE); v["queryIdx"] = [4, 2, 4, 0, 9]
     assert oracle.in_match_vec(v, 6).tolist() == [3, -1, 1, -1, 0, -1]
     assert oracle.in_match_vec(v[:0], 3).tolist() == [-1, -1, -1]
+
+
+def test_rgb_cloud_known_values(oracle):
+    depth = np.array([[0, 65535], [13107, 100]], np.uint16)             # (y, x)
+    bgr = np.arange(12, dtype=np.uint8).reshape(2, 2, 3)
+    c = oracle.rgb_cloud(depth, bgr, 0.5, 0.25, 2.0, 4.0, 10.0)
+    # index u*h + v: (u0,v0) (u0,v1) (u1,v0) (u1,v1)
+    assert c["z"].tolist() == [0.0, float(np.float32(13107 * (10.0 / 65535.0))), 10.0, float(np.float32(100 * (10.0 / 65535.0)))]
+    f = np.float32
+    assert c["x"][2] == (f(1.0) - f(0.5)) * f(10.0) * f(0.5) and c["y"][2] == (f(0.0) - f(0.25)) * f(10.0) * f(0.25)
+    assert c["b"].tolist() == [0, 6, 3, 9] and c["g"].tolist() == [1, 7, 4, 10] and c["r"].tolist() == [2, 8, 5, 11]
+    assert (c["a"] == 255).all() and (c["w"] == 1.0).all() and (c["pad"] == 0).all()
+    # the driver multiplies in double and narrows once: differs from the float product for some raw values
+    s32 = np.float32(10.0 / 65535.0)
+    raw = np.arange(1, 65536, dtype=np.uint16).reshape(1, -1)
+    z = oracle.rgb_cloud(raw, np.zeros((1, 65535, 3), np.uint8), 0, 0, 1, 1, 10.0)["z"]
+    assert np.array_equal(z, (raw[0].astype(np.float64) * (10.0 / 65535.0)).astype(np.float32))
+    assert (z != raw[0].astype(np.float32) * s32).any()
