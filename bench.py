@@ -261,7 +261,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched-matching", action="store_true", help="skip the configs[3]/[4] matching section")
     ap.add_argument("--sync-steps", action="store_true", help="host waits for every step (latency mode)")
-    ap.add_argument("--streams", type=int, default=2, help="steps in flight: step i runs on handle pair i %% streams, each pair on its own HIP stream")
+    ap.add_argument("--streams", type=int, default=3, help="steps in flight: step i runs on handle pair i %% streams, each pair on its own HIP stream")
     ap.add_argument("--all-kernel-events", action="store_true", help="hipEvent pairs around every kernel in the timed region (slower)")
     args = ap.parse_args()
 

@@ -46,7 +46,7 @@ __device__ __forceinline__ int qt_block_scan_excl(int v, int* wsum, int& total)
 template <int MAXA>
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
 {
-    constexpr int IT = MAXA / kQtThreads;
+    constexpr int IT = MAXA >= kQtThreads ? MAXA / kQtThreads : 1;     // nodes per thread (MAXA = 256: threads 256.. hold no node)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // ---- LDS carve (all offsets multiples of 16)
     unsigned long long* skeys = (unsigned long long*)smem;                 // MAXA   sort keys / final best
@@ -349,13 +349,20 @@ size_t quadtree_lds_bytes(int maxa)
 
 int launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipStream_t s)
 {
-    static bool attrSet = false;
+    static bool attrSetDev[64] = {};                  // the attribute belongs to the device's copy of the kernel
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& attrSet = attrSetDev[dev & 63];
     if (!attrSet) {
+        (void)hipFuncSetAttribute((const void*)k_quadtree<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(256));
         (void)hipFuncSetAttribute((const void*)k_quadtree<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(1024));
         (void)hipFuncSetAttribute((const void*)k_quadtree<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(2048));
         attrSet = true;
     }
-    if (maxAlive <= 1024) hipLaunchKernelGGL(k_quadtree<1024>, dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(1024), s, a);
+    // the smallest node capacity that holds quota + 3: 19 KB of LDS at 256 nodes (73 KB at 1024), so that the workgroups of
+    // other kernels (k_fast, k_describe of the step in flight beside this one) still fit on the CU
+    if (maxAlive <= 256) hipLaunchKernelGGL(k_quadtree<256>, dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(256), s, a);
+    else if (maxAlive <= 1024) hipLaunchKernelGGL(k_quadtree<1024>, dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(1024), s, a);
     else if (maxAlive <= 2048) hipLaunchKernelGGL(k_quadtree<2048>, dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(2048), s, a);
     else return -1;
     return 0;

@@ -146,3 +146,28 @@ def test_match_by_project_empty_inputs(mods, fm):
     assert not ok and len(m) == 0
     ok, m = fm.MatchByProject(P3, dq, np.zeros((0, 2)), None, 5.0, K, R, t)
     assert not ok and len(m) == 0
+
+
+def test_full_size_blocks_by_properties(mods, fm):
+    """BASELINE config 5 block size (8000 x 8000 descriptors): the oracle checks a sample of query rows, the rest is held
+    by size-independent properties (self-match is the identity at distance 0, best <= second, mutual-NN lists are
+    symmetric, the BF filter is the stated function of the raw 1-NN)"""
+    S, synth, O = mods
+    q, t = synth.descriptor_sets(77, 8000, 8000)
+    idx, d1, d2 = fm.knn2_raw(q, t)
+    pick = np.arange(0, 8000, 125)
+    ri, r1, r2 = O.knn2_raw(q[pick], t)
+    assert np.array_equal(idx[pick], ri) and np.array_equal(d1[pick], r1) and np.array_equal(d2[pick], r2)
+    assert (d1 <= d2).all() and (idx >= 0).all() and (idx < 8000).all()
+    si, s1, _ = fm.knn2_raw(t, t)
+    assert (s1 == 0).all()
+    dup = si != np.arange(8000)                                     # only exact duplicate rows may point to an earlier copy
+    assert (si[dup] < np.arange(8000)[dup]).all() and all((t[a] == t[b]).all() for a, b in zip(np.flatnonzero(dup), si[dup]))
+    ok, m = fm.MatchByBruteForce(q, t)
+    lim = max(2 * int(d1.min()), 30)
+    keep = d1 < lim
+    assert np.array_equal(m["queryIdx"], np.flatnonzero(keep)) and np.array_equal(m["trainIdx"], idx[keep])
+    ok, c = fm.MatchByCrossCheck(q, t)
+    ok, cr = fm.MatchByCrossCheck(t, q)
+    fwd = set(zip(c["queryIdx"].tolist(), c["trainIdx"].tolist())); rev = set(zip(cr["trainIdx"].tolist(), cr["queryIdx"].tolist()))
+    assert fwd == rev and len(fwd) > 4000
