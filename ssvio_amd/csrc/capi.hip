@@ -1131,10 +1131,10 @@ static int bow_grow(ssvio_matcher* m, size_t rows)
 }
 
 // order the rows of `nsets` transformed sets by (node id, index); same row indexing as bow_run
-static void bow_sort(ssvio_matcher* m, int setStrideRows, const int* d_counts, int nsets, size_t rowBase)
+static void bow_sort(ssvio_matcher* m, int setStrideRows, const int* d_counts, int nsets, int maxRows, size_t rowBase)
 {
     BowSortArgs a{};
-    a.gnode = m->d_gnode + rowBase; a.setStrideRows = setStrideRows; a.counts = d_counts;
+    a.gnode = m->d_gnode + rowBase; a.setStrideRows = setStrideRows; a.counts = d_counts; a.maxRows = maxRows;
     a.sortedIdx = m->d_sortIdx + rowBase; a.sortedNode = m->d_sortNode + rowBase;
     ProfScope p(m->prof, "k_bow_sort", m->stream);
     launch_bow_sort(a, nsets, m->stream);
@@ -1146,7 +1146,7 @@ static void bow_run(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* d_des
 {
     BowArgs a{};
     a.v = vocab_dev(v); a.nidLevel = v->L - levelsup;
-    a.desc = (const uint4*)d_desc; a.setStrideRows = setStrideRows; a.counts = d_counts; a.nsets = nsets;
+    a.desc = (const uint4*)d_desc; a.setStrideRows = setStrideRows; a.counts = d_counts; a.nsets = nsets; a.maxRows = maxRows;
     a.word = m->d_bowWord + rowBase; a.node = m->d_bowNode + rowBase; a.weight = m->d_bowWeight + rowBase; a.gnode = m->d_gnode + rowBase;
     ProfScope p(m->prof, "k_bow_transform", m->stream);
     launch_bow_transform(a, maxRows, m->stream);
@@ -1265,13 +1265,13 @@ int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, i
     bow_run(m, v, m->d_q, 0, m->d_counts2, 1, nq, levelsup, 0);               // ComputeBoWVector(desp1), :68
     bow_run(m, v, m->d_t, 0, m->d_counts2 + 1, 1, nt, levelsup, (size_t)nq);  // ComputeBoWVector(desp2), :69
     if (std::max(nq, nt) <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED")) {
-        bow_sort(m, 0, m->d_counts2, 1, 0);
-        bow_sort(m, 0, m->d_counts2 + 1, 1, (size_t)nq);
+        bow_sort(m, 0, m->d_counts2, 1, nq, 0);
+        bow_sort(m, 0, m->d_counts2 + 1, 1, nt, (size_t)nq);
         SortedMatchArgs g{};
         g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t;
         g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx + nq; g.tSortedNode = m->d_sortNode + nq;
         g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
-        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq; g.maxT = nt;
         g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
         ProfScope p(m->prof, "k_match_sorted", s);
         launch_match_sorted(g, nq, nt, 1, s);
@@ -1279,7 +1279,7 @@ int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, i
         GroupedArgs g{};
         g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + nq;
         g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
-        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq; g.maxT = nt;
         g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
         ProfScope p(m->prof, "k_match_grouped", s);
         launch_match_grouped(g, nq, 1, s);
@@ -1330,12 +1330,12 @@ int ssvio_match_dbow_batch_dev(ssvio_matcher* m, const ssvio_vocab* v, const voi
     rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
     bow_run(m, v, (const uint8_t*)d_desc, set_stride_rows, d_counts, nsets, max_rows, levelsup, 0);   // once per set, not per pair
     if (max_rows <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED")) {
-        bow_sort(m, set_stride_rows, d_counts, nsets, 0);
+        bow_sort(m, set_stride_rows, d_counts, nsets, max_rows, 0);
         SortedMatchArgs g{};
         g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc;
         g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx; g.tSortedNode = m->d_sortNode;
         g.qSetStrideRows = set_stride_rows; g.tSetStrideRows = set_stride_rows; g.qcounts = d_counts; g.tcounts = d_counts; g.pairs = m->d_pairs;
-        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows; g.maxT = max_rows;
         g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
         ProfScope p(m->prof, "k_match_sorted", s);
         launch_match_sorted(g, max_rows, max_rows, npairs, s);
@@ -1343,7 +1343,7 @@ int ssvio_match_dbow_batch_dev(ssvio_matcher* m, const ssvio_vocab* v, const voi
         GroupedArgs g{};
         g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode;
         g.qSetStrideRows = set_stride_rows; g.tSetStrideRows = set_stride_rows; g.qcounts = d_counts; g.tcounts = d_counts; g.pairs = m->d_pairs;
-        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows; g.maxT = max_rows;
         g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
         ProfScope p(m->prof, "k_match_grouped", s);
         launch_match_grouped(g, max_rows, npairs, s);

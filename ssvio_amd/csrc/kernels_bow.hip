@@ -15,7 +15,7 @@ namespace ssvio {
 __global__ __launch_bounds__(256) void k_bow_transform(BowArgs a)
 {
     const int set = blockIdx.y;
-    const int n = a.counts[set];
+    const int n = min(a.counts[set], a.maxRows);
     const int g = threadIdx.x & 15;
     const int f = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (f >= n) return;                                               // uniform over the 16 lanes of a feature
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_match_grouped(GroupedArgs a)
     const int lane = threadIdx.x & 63;
     const int pair = blockIdx.y;
     const int qset = a.pairs ? a.pairs[2 * pair] : 0, tset = a.pairs ? a.pairs[2 * pair + 1] : 0;
-    const int nq = a.qcounts[qset], nt = a.tcounts[tset];
+    const int nq = min(a.qcounts[qset], a.maxRows), nt = min(a.tcounts[tset], a.maxT);
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= nq) return;                                              // wave-uniform
     const size_t qrow = (size_t)qset * a.qSetStrideRows + i, tbase = (size_t)tset * a.tSetStrideRows;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_grouped_compact(GroupedArgs a)
     __shared__ int32_t tile[1024];
     const int pair = blockIdx.y;
     const int qset = a.pairs ? a.pairs[2 * pair] : 0;
-    const int nq = a.qcounts[qset];
+    const int nq = min(a.qcounts[qset], a.maxRows);
     if ((int)(blockIdx.x * 256) >= max(nq, 1)) return;               // block-uniform
     const int32_t* keepNode = a.keepNode + (size_t)pair * a.maxRows;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void k_bow_sort(BowSortArgs a)
 {
     __shared__ unsigned long long key[kBowSortMax];
     const int set = blockIdx.x, tid = threadIdx.x;
-    const int n = min(a.counts[set], kBowSortMax);
+    const int n = min(min(a.counts[set], a.maxRows), kBowSortMax);
     const size_t base = (size_t)set * a.setStrideRows;
     int P = 1024;
     while (P < n) P <<= 1;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_match_sorted(SortedMatchArgs a)
     extern __shared__ int32_t lds[];
     const int pair = blockIdx.y;
     const int qset = a.pairs ? a.pairs[2 * pair] : 0, tset = a.pairs ? a.pairs[2 * pair + 1] : 0;
-    const int nq = a.qcounts[qset], nt = min(a.tcounts[tset], kBowSortMax);
+    const int nq = min(a.qcounts[qset], a.maxRows), nt = min(min(a.tcounts[tset], a.maxT), kBowSortMax);
     if ((int)(blockIdx.x * 256) >= nq) return;                          // block-uniform
     const size_t qb = (size_t)qset * a.qSetStrideRows, tb = (size_t)tset * a.tSetStrideRows;
     int32_t* sNode = lds; int32_t* sIdx = lds + nt;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_sorted_compact(SortedMatchArgs a)
     __shared__ int wsum[4];
     const int pair = blockIdx.x;
     const int qset = a.pairs ? a.pairs[2 * pair] : 0, tset = a.pairs ? a.pairs[2 * pair + 1] : 0;
-    const int nq = a.tcounts[tset] > 0 ? a.qcounts[qset] : 0;           // :61-63: nothing with an empty train set
+    const int nq = a.tcounts[tset] > 0 ? min(a.qcounts[qset], a.maxRows) : 0;   // :61-63: nothing with an empty train set
     const size_t ob = (size_t)pair * a.maxRows;
     int written = 0;
     for (int r0 = 0; r0 < nq; r0 += 256) {

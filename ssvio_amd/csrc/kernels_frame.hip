@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs a)
     const ssvio_keypoint* curK = a.kps + (size_t)curSet * a.kpStride;
     const uint16_t* lastD = a.depth + (size_t)lastSet * a.depthFrameStride;
     const uint16_t* curD = a.depth + (size_t)curSet * a.depthFrameStride;
-    const int nLast = a.kpCounts[lastSet], nCur = a.kpCounts[curSet];
+    const int nLast = min(a.kpCounts[lastSet], a.kpStride), nCur = min(a.kpCounts[curSet], a.kpStride);
     const size_t ob = (size_t)pair * a.maxRows;
     int nPre = 0, nFin = 0;
     for (int i0 = 0; i0 < nm; i0 += 256) {

@@ -49,6 +49,7 @@ struct VocabDev {
 struct BowArgs {
     VocabDev v; int nidLevel;                  // L - levelsup
     const uint4* desc; int setStrideRows; const int* counts; int nsets;
+    int maxRows;                               // counts[] are clamped to this (rows a set can hold)
     int32_t* word; int32_t* node; double* weight;   // per feature, same row indexing as desc
     int32_t* gnode;                            // node id, or -1 for a stopped word (weight <= 0): the grouping key
 };
@@ -58,7 +59,7 @@ void launch_bow_transform(const BowArgs& a, int maxRows, hipStream_t s);
 struct GroupedArgs {
     const uint4* qdesc; const uint4* tdesc; const int32_t* qgnode; const int32_t* tgnode;
     int qSetStrideRows, tSetStrideRows; const int* qcounts; const int* tcounts; const int* pairs;
-    int threshold; float nnRatio; int maxRows;
+    int threshold; float nnRatio; int maxRows, maxT;   // maxRows: query rows per pair (output stride); maxT: train rows a set can hold
     ssvio_dmatch* cand; int32_t* keepNode;     // [pair][maxRows]: candidate match; node id if it is kept else -1
     ssvio_dmatch* out; int* nout;              // [pair][maxRows], [pair]
 };
@@ -68,6 +69,7 @@ void launch_match_grouped(const GroupedArgs& a, int maxQ, int npairs, hipStream_
 constexpr int kBowSortMax = 8192;
 struct BowSortArgs {
     const int32_t* gnode; int setStrideRows; const int* counts;      // per set: gnode + set * setStrideRows, counts[set] rows
+    int maxRows;                                                     // counts[] are clamped to this
     int32_t* sortedIdx; int32_t* sortedNode;                         // same indexing: rank r -> feature index / its key
 };
 void launch_bow_sort(const BowSortArgs& a, int nsets, hipStream_t s);
@@ -75,7 +77,7 @@ struct SortedMatchArgs {
     const uint4* qdesc; const uint4* tdesc;
     const int32_t* qSortedIdx; const int32_t* qSortedNode; const int32_t* tSortedIdx; const int32_t* tSortedNode;
     int qSetStrideRows, tSetStrideRows; const int* qcounts; const int* tcounts; const int* pairs;
-    int threshold; float nnRatio; int maxRows;
+    int threshold; float nnRatio; int maxRows, maxT;
     ssvio_dmatch* cand; int32_t* keep;         // [pair][maxRows], indexed by the query's rank
     ssvio_dmatch* out; int* nout;
 };
