@@ -167,6 +167,8 @@ struct ssvio_orb {
     std::unique_ptr<WorkerPool> pool;
     int lastBatch = 0;
     bool haveResults = false;
+    // the launch sequence behind k_level0 as a hipGraph (one per batch size and buffer generation), replayed by later calls
+    hipGraphExec_t gexec = nullptr; int gBatch = 0; unsigned gGen = 0, allocGen = 1; bool graphFailed = false;
 };
 
 static void orb_free_buffers(ssvio_orb* h)
@@ -176,6 +178,7 @@ static void orb_free_buffers(ssvio_orb* h)
     dfree(h->d_sel); dfree(h->d_selCount); dfree(h->d_kpCount); dfree(h->d_kpOut); dfree(h->d_desc);
     hfree(h->h_kpCount);
     h->batchCap = 0; h->inBytes = 0; h->haveResults = false;
+    ++h->allocGen;                                   // a captured graph holds the old addresses
 }
 
 static void fill_klevels(const PyramidGeom& g, KLevels& k)
@@ -343,13 +346,11 @@ static int orb_host_quadtree(ssvio_orb* h, int batch)
     return SSVIO_OK;
 }
 
-// the whole pipeline for `batch` frames whose level-0 images are already in d_pyr; everything is
-// enqueued on the stream, the host only waits for the per-frame keypoint counts at the end
-static int orb_run(ssvio_orb* h, int batch, bool wait = true)
+// the launch sequence for `batch` frames whose level-0 images are already in d_pyr
+static int orb_enqueue(ssvio_orb* h, int batch)
 {
     const PyramidGeom& g = h->geom;
     hipStream_t s = h->stream;
-    h->hostRawValid = false;
     // d_rawCount / d_cellIni were cleared by k_level0
     for (int l = 1; l < g.nlevels; ++l) {
         ProfScope p(h->prof, "k_resize", s);
@@ -387,6 +388,42 @@ static int orb_run(ssvio_orb* h, int batch, bool wait = true)
         launch_describe(h->d_pyr, h->d_blur, g.frameBytes, h->kl, h->d_sel, h->d_selCount, h->kpCap, h->kpCap, h->d_kpOut, h->d_desc,
                         h->d_kpCount, h->d_kpCountHost, batch, s);
     }
+    return SSVIO_OK;
+}
+
+static bool graphs_enabled()
+{
+    static const bool on = [] { const char* e = getenv("SSVIO_GRAPH"); return e && e[0] == '1'; }();
+    return on;
+}
+
+// The whole pipeline behind k_level0; everything is enqueued on the stream, the host only waits for the per-frame keypoint
+// counts at the end.  With SSVIO_GRAPH=1 the ~12 launches and the fork / join with the side stream are captured once per
+// (batch size, buffer generation) into a hipGraph and replayed.  Off by default: on this stack (ROCm 7.2, MI355X) the replay
+// is slower than the plain launches (one VGA frame per call 158 vs 150 us, 64-frame steps 181 k vs 193 k frames/s,
+// DESIGN.md section 4).  Never with the host quadtree (it waits in the middle) or while kernels are bracketed by profiling events.
+static int orb_run(ssvio_orb* h, int batch, bool wait = true)
+{
+    hipStream_t s = h->stream;
+    h->hostRawValid = false;
+    bool launched = false;
+    if (graphs_enabled() && !h->hostQuadtree && !h->prof.enabled && !h->graphFailed) {
+        if (!h->gexec || h->gBatch != batch || h->gGen != h->allocGen) {
+            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+            quadtree_prepare();                                   // function attributes are set outside the capture
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = orb_enqueue(h, batch);
+                const hipError_t e = hipStreamEndCapture(s, &graph);
+                if (rc == SSVIO_OK && e == hipSuccess && graph && hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    h->gBatch = batch; h->gGen = h->allocGen;
+                } else { h->gexec = nullptr; h->graphFailed = true; (void)hipGetLastError(); }
+                if (graph) (void)hipGraphDestroy(graph);
+            } else { h->graphFailed = true; (void)hipGetLastError(); }
+        }
+        if (h->gexec) { SSVIO_HIP(hipGraphLaunch(h->gexec, s)); launched = true; }
+    }
+    if (!launched) { const int rc = orb_enqueue(h, batch); if (rc) return rc; }
     // the counts reach the host through k_describe's stores into the pinned, device-mapped h_kpCount
     h->lastBatch = batch; h->haveResults = true; h->pending = true;
     if (wait) { SSVIO_HIP(hipStreamSynchronize(s)); h->pending = false; }
@@ -446,6 +483,7 @@ int ssvio_orb_create(const ssvio_orb_params* params, int device, ssvio_orb** out
 void ssvio_orb_destroy(ssvio_orb* h)
 {
     if (!h) return;
+    if (h->gexec) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     h->prof.resolve(); h->prof.destroy();

@@ -170,6 +170,7 @@ void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int le
 void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int tilesPerFrame /* of the chosen form */, bool tall, int cellsPerFrame, size_t rawPerFrame,
                  int iniTh, int minTh, uint2* raw, int* rawCount, int* cellIni, int batch, hipStream_t s);
 int  launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipStream_t s);
+void quadtree_prepare();
 void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int stripsPerFrame, int batch, hipStream_t s);
 // sel: per level lists {x | y<<16, level | resp<<8} at f*selPerFrame + selBase[l]; selCount[f][kMaxLevels]
 void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl,

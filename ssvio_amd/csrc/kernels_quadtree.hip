@@ -347,7 +347,8 @@ size_t quadtree_lds_bytes(int maxa)
     return (size_t)maxa * (8 + 16 + 8 + 8 + 16 + 4 * 4 + 1) + sizeof(QtShared) + 64;
 }
 
-int launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipStream_t s)
+// raises the dynamic-LDS limit of the instantiations on the current device (once per device)
+void quadtree_prepare()
 {
     static bool attrSetDev[64] = {};                  // the attribute belongs to the device's copy of the kernel
     int dev = 0;
@@ -359,6 +360,11 @@ int launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipSt
         (void)hipFuncSetAttribute((const void*)k_quadtree<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(2048));
         attrSet = true;
     }
+}
+
+int launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipStream_t s)
+{
+    quadtree_prepare();
     // the smallest node capacity that holds quota + 3: 19 KB of LDS at 256 nodes (73 KB at 1024), so that the workgroups of
     // other kernels (k_fast, k_describe of the step in flight beside this one) still fit on the CU
     if (maxAlive <= 256) hipLaunchKernelGGL(k_quadtree<256>, dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(256), s, a);
