@@ -196,7 +196,7 @@ static void fill_klevels(const PyramidGeom& g, KLevels& k)
         K.rawBase = (unsigned)L.slotBase; K.rawCap = (unsigned)L.slotCap * L.nCols * L.nRows;
         K.selBase = L.selBase; K.nIni = L.nIni; K.hX = L.hX;
         K.wCellMagic = ((1 << 20) + L.wCell - 1) / L.wCell; K.hCellMagic = ((1 << 20) + L.hCell - 1) / L.hCell;
-        for (int i = 0; i < 5; ++i) K.rootX[i] = L.rootX[i];
+        for (int i = 0; i <= kMaxRoots; ++i) K.rootX[i] = L.rootX[i];
     }
     KLevel& E = k.lv[g.nlevels];
     E.cellBase = g.cellsPerFrame; E.fastTileBase = g.fastTilesPerFrame; E.fastTileBaseT = g.fastTilesPerFrameT; E.blurStripBase = g.blurStripsPerFrame;

@@ -15,6 +15,7 @@ constexpr int kEdge = 19;          // EDGE_THRESHOLD, src/Feature.cpp:14
 constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE, src/Feature.cpp:13
 constexpr int kMinBorder = 16;     // EDGE_THRESHOLD - 3, src/Feature.cpp:835
 constexpr int kPadX = 4;          // reflect-101 columns kept on both sides of every level row (for k_blur)
+constexpr int kMaxRoots = 8;       // quadtree roots per level = round(width / height) of the tested region (src/Feature.cpp:574)
 constexpr int kMaxCellDim = 64;    // interior of a FAST cell window never exceeds 59 px (see geometry.cpp)
 
 void set_error(const char* fmt, ...);
@@ -37,7 +38,7 @@ struct LevelGeom {
     int slotCap;              // worst-case keypoints per cell after NMS
     size_t slotBase;          // first raw-list entry of this level within a frame (= sum of cells * slotCap)
     int selBase;              // first selected-keypoint entry of this level within a frame
-    int nIni; float hX; int rootX[5];   // quadtree roots
+    int nIni; float hX; int rootX[kMaxRoots + 1];   // quadtree roots
     int quota;                // mnFeaturesPerLevel
     float scale;              // mvScaleFactor
     int kpSize;               // (int)(15*scale)
@@ -72,7 +73,7 @@ struct KLevel {
     unsigned long long offset;        // byte offset of pixel (0,0) inside a frame's pyramid
     unsigned int rawBase, rawCap;     // this level's region of the raw candidate list of a frame (entries)
     int selBase;                      // this level's region of the selected-keypoint list of a frame
-    int nIni; float hX; int rootX[5]; // quadtree roots (src/Feature.cpp:574-593)
+    int nIni; float hX; int rootX[kMaxRoots + 1]; // quadtree roots (src/Feature.cpp:574-593)
     int wCellMagic, hCellMagic;       // ceil(2^20 / cell size): (n * magic) >> 20 == n / cell for n < 4096
 };
 struct KLevels {
@@ -90,6 +91,8 @@ struct QtArgs {
     uint2* sel; int* selCount; int selPerFrame;
     int batch;
 };
+
+static_assert(sizeof(QtArgs) <= 4096, "kernel arguments are passed by value: 4 KB limit");
 
 struct ExtractorTables {
     int nfeatures, nlevels, iniTh, minTh;

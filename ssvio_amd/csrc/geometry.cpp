@@ -76,7 +76,7 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
         }
         L.wCell = (int)std::ceil(fw / L.nCols); L.hCell = (int)std::ceil(fh / L.nRows);
         const int nIni = (int)std::round(fw / fh);                    // src/Feature.cpp:574
-        if (nIni > 4) { set_error("level %d aspect ratio %g needs %d quadtree roots (max 4 supported)", l, fw / fh, nIni); return SSVIO_ERR_GEOMETRY; }
+        if (nIni > kMaxRoots) { set_error("level %d aspect ratio %g needs %d quadtree roots (max %d supported)", l, fw / fh, nIni, kMaxRoots); return SSVIO_ERR_GEOMETRY; }
         if (nIni < 1) { set_error("level %d aspect ratio %g rounds to zero quadtree roots (src/Feature.cpp:574)", l, fw / fh); return SSVIO_ERR_GEOMETRY; }
         if (L.wCell > kMaxCellDim || L.hCell > kMaxCellDim) { set_error("internal: cell %dx%d exceeds %d", L.wCell, L.hCell, kMaxCellDim); return SSVIO_ERR_GEOMETRY; }
         L.pitch = ((L.w + 63) / 64) * 64 + 128;         // 64-B aligned rows, 64 B of slack on both sides (pad columns, vector reads)

@@ -1,0 +1,87 @@
+"""CPU: randomised (hypothesis) checks of the host-side logic against the oracle, and of oracle invariants the
+domain offers (lowest-index ties, order preservation, idempotence).  Bounded example counts: the whole file runs in seconds."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+CFG = dict(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+
+
+@settings(**CFG)
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 1500), N=st.integers(1, 400), w=st.integers(64, 700), h=st.integers(64, 500))
+def test_host_quadtree_equals_oracle_on_random_point_sets(oracle, seed, n, N, w, h):
+    import ssvio_amd
+    if round(w / h) < 1:
+        return                                                      # nIni = 0: division by zero in the reference (:575)
+    rng = np.random.default_rng(seed)
+    flat = np.sort(rng.choice(w * h, size=min(n, w * h), replace=False))
+    xs = (flat % w).astype(np.float32); ys = (flat // w).astype(np.float32)
+    resp = rng.integers(7, 40, len(flat)).astype(np.float32)         # few distinct responses: ties are common
+    want, _ = oracle.distribute_octtree(xs, ys, resp, 0, w, 0, h, N)
+    got = ssvio_amd.distribute_octtree(xs, ys, resp, 0, w, 0, h, N)
+    assert np.array_equal(got, want)
+    assert len(set(got.tolist())) == len(got) and len(got) <= min(len(flat), N + 3)
+
+
+@settings(**CFG)
+@given(seed=st.integers(0, 2**31 - 1), nq=st.integers(1, 60), nt=st.integers(1, 60), dup=st.booleans())
+def test_matcher_oracle_invariants(oracle, seed, nq, nt, dup):
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    if dup and nt > 1:
+        t[nt // 2:] = t[:nt - nt // 2]                              # duplicated train rows: ties everywhere
+    q = t[rng.integers(0, nt, nq)] ^ (rng.random((nq, 32)) < 0.05).astype(np.uint8)
+    idx, d1, d2 = oracle.knn2_raw(q, t)
+    D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    assert np.array_equal(d1, D.min(1)) and np.array_equal(idx, D.argmin(1))          # argmin = lowest index on ties
+    part = np.sort(D, axis=1)
+    assert np.array_equal(d2, part[:, 1] if nt > 1 else np.full(nq, 256))
+    bi, bd = oracle.bf_nn(q, t)
+    assert np.array_equal(bi, idx) and np.array_equal(bd, d1)
+    m = oracle.match_bruteforce(q, t)
+    lim = max(2 * int(d1.min()), 30)
+    assert np.array_equal(m["queryIdx"], np.flatnonzero(d1 < lim))
+    c = oracle.match_crosscheck(q, t)
+    for a, b in zip(c["queryIdx"], c["trainIdx"]):
+        assert D[a].argmin() == b and D[:, b].argmin() == a
+
+
+@settings(**CFG)
+@given(seed=st.integers(0, 2**31 - 1), nlast=st.integers(0, 80), ncur=st.integers(0, 80), nkp=st.integers(1, 40))
+def test_track_map_points_and_in_match_vec_against_definitions(oracle, seed, nlast, ncur, nkp):
+    rng = np.random.default_rng(seed)
+    last = np.zeros(nlast, oracle.DM_DTYPE); cur = np.zeros(ncur, oracle.DM_DTYPE)
+    last["queryIdx"] = rng.integers(0, nkp, nlast); last["trainIdx"] = rng.integers(0, nkp, nlast)
+    cur["queryIdx"] = rng.integers(0, nkp, ncur); cur["trainIdx"] = rng.integers(0, nkp, ncur)
+    out = oracle.track_map_points(last, cur)
+    want = []
+    for l in last:
+        hit = np.flatnonzero(cur["trainIdx"] == l["queryIdx"])
+        if len(hit):
+            want.append((int(cur["queryIdx"][hit[0]]), int(l["trainIdx"])))
+    assert list(zip(out["queryIdx"].tolist(), out["trainIdx"].tolist())) == want
+    pos = oracle.in_match_vec(last, nkp)
+    for i in range(nkp):
+        hit = np.flatnonzero(last["queryIdx"] == i)
+        assert pos[i] == (hit[0] if len(hit) else -1)
+
+
+@settings(**CFG)
+@given(seed=st.integers(0, 2**31 - 1), k=st.integers(2, 6), L=st.integers(1, 4), n=st.integers(1, 80), scoring=st.integers(0, 5), weighting=st.integers(0, 3))
+def test_host_bow_vector_equals_oracle(oracle, seed, k, L, n, scoring, weighting):
+    from ssvio_amd import synth
+    from ssvio_amd.vocabulary import Vocabulary
+    par, desc, w = synth.vocabulary_tables(seed % 1000, k, L, early_leaf_p=0.2, stop_p=0.1)
+    v = Vocabulary(k, L, par, desc, w, scoring=scoring, weighting=weighting)
+    ov = oracle.Vocabulary(k, L, par, desc, w, v.word, scoring, weighting)
+    d = synth.descriptors_near_leaves(seed, n, par, desc, 0.05)
+    word, node, weight = ov.transform(d, min(L, 2))
+    a, b = v.bow_vector(word, weight), ov.bow_vector(word, weight)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # descent invariant: the reported node is an ancestor-or-self of the word's leaf at the asked level (or 0)
+    leaf_of_word = {int(wd): i for i, wd in enumerate(v.word) if wd >= 0}
+    for f in range(n):
+        chain = [leaf_of_word[int(word[f])]]
+        while par[chain[-1]] >= 0:
+            chain.append(int(par[chain[-1]]))
+        assert int(node[f]) in chain
