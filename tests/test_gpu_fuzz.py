@@ -55,3 +55,59 @@ def test_random_configuration_equals_oracle(w, h, sf, nl, nf, ini, mn, seed):
     for f in (0, 2):
         assert ns[f] == len(rk) and np.array_equal(ks[f, :ns[f]].view(np.uint8), rk.view(np.uint8)) and np.array_equal(ds[f, :ns[f]], rd)
     g.close()
+
+
+def _match_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(1, 3000)), int(rng.integers(1, 3000)), int(rng.integers(0, 1 << 30))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("nq,nt,seed", _match_cases(16, 99))
+def test_random_match_shapes_equal_oracle(nq, nt, seed):
+    import ssvio_amd as S
+    from ssvio_amd import synth
+    from oracle import oracle as O
+    q, t = synth.descriptor_sets(seed, nq, nt, flip_p=0.05 + (seed % 7) * 0.02)
+    if seed % 3 == 0 and nt > 4:
+        t[nt // 2:] = t[:nt - nt // 2]                               # duplicated rows: lowest-index ties
+    th, ratio = [(50, 0.6), (30, 0.8), (80, 0.95)][seed % 3]
+    fm = S.FeatureMatching(None, {"Threshold": th, "NNRatio": ratio})
+    b = lambda a: np.ascontiguousarray(a).view(np.uint8)
+    idx, d1, d2 = fm.knn2_raw(q, t)
+    ri, r1, r2 = O.knn2_raw(q, t)
+    assert np.array_equal(idx, ri) and np.array_equal(d1, r1) and np.array_equal(d2, r2)
+    assert np.array_equal(b(fm.MatchByBruteForce(q, t)[1]), b(O.match_bruteforce(q, t)))
+    assert np.array_equal(b(fm.MatchByKnnRatio(q, t)[1]), b(O.match_knn2_ratio(q, t, th, ratio)))
+    assert np.array_equal(b(fm.MatchByCrossCheck(q, t)[1]), b(O.match_crosscheck(q, t)))
+    fm.close()
+
+
+@pytest.mark.parametrize("seed,mode", [(1, 0), (2, 1), (3, 2), (4, 0)])
+def test_ragged_batches_equal_oracle(seed, mode):
+    """device-resident batch with sets of very different sizes (including empty ones) and repeated / self pairs"""
+    import torch
+    import ssvio_amd as S
+    from ssvio_amd import synth, _lib as L
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    nsets, stride = 9, 1300
+    counts = [int(c) for c in rng.choice([0, 1, 2, 63, 64, 65, 255, 256, 257, 700, 1024, 1300], nsets)]
+    base = synth.descriptor_sets(seed + 10, 8, 1300)[1]
+    sets = []
+    for s, c in enumerate(counts):
+        d = base[rng.permutation(1300)[:c]] ^ np.packbits(rng.random((c, 256)) < 0.04, axis=1, bitorder="little")
+        sets.append(np.ascontiguousarray(d))
+    buf = np.zeros((nsets, stride, 32), np.uint8)
+    for s, d in enumerate(sets):
+        buf[s, :len(d)] = d
+    pairs = np.array([[rng.integers(0, nsets), rng.integers(0, nsets)] for _ in range(14)] + [[0, 0], [3, 3]], np.int32)
+    fm = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
+    d_desc = torch.from_numpy(buf).cuda(); d_cnt = torch.tensor(counts, dtype=torch.int32).cuda()
+    fm.match_batch_dev(d_desc, stride, stride, d_cnt, pairs, mode)
+    fm.sync()
+    out, n = fm.fetch_batch()
+    ref = [O.match_bruteforce, lambda a, c: O.match_knn2_ratio(a, c, 50, 0.6), O.match_crosscheck][mode]
+    for p, (a, c) in enumerate(pairs):
+        want = ref(sets[a], sets[c])
+        assert n[p] == len(want) and np.array_equal(out[p, :n[p]].view(np.uint8), want.view(np.uint8)), (p, counts[a], counts[c])
+    fm.close()
