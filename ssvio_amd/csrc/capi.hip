@@ -154,6 +154,7 @@ struct ssvio_orb {
     uint2* d_raw = nullptr; int* d_rawCount = nullptr; int* d_cellIni = nullptr;     // FAST output: unordered candidate lists
     uint32_t* d_kval = nullptr; uint32_t* d_kord = nullptr; uint32_t* d_knode = nullptr;   // quadtree per-key scratch
     uint2* d_sel = nullptr; int* d_selCount = nullptr;                                  // selected keypoints per level
+    unsigned char* d_qtNode = nullptr; size_t qtNodeStride = 0;                         // k_quadtree node arrays in HBM (quotas > 2045 per level)
     int* d_kpCount = nullptr;
     ssvio_keypoint* d_kpOut = nullptr; uint8_t* d_desc = nullptr;
     int* h_kpCount = nullptr; int* d_kpCountHost = nullptr;   // pinned host array and its device address
@@ -175,7 +176,7 @@ static void orb_free_buffers(ssvio_orb* h)
 {
     dfree(h->d_in); dfree(h->d_pyr); dfree(h->d_blur); dfree(h->d_tabs);
     dfree(h->d_raw); dfree(h->d_rawCount); dfree(h->d_cellIni); dfree(h->d_kval); dfree(h->d_kord); dfree(h->d_knode);
-    dfree(h->d_sel); dfree(h->d_selCount); dfree(h->d_kpCount); dfree(h->d_kpOut); dfree(h->d_desc);
+    dfree(h->d_sel); dfree(h->d_selCount); dfree(h->d_kpCount); dfree(h->d_kpOut); dfree(h->d_desc); dfree(h->d_qtNode);
     hfree(h->h_kpCount);
     h->batchCap = 0; h->inBytes = 0; h->haveResults = false;
     ++h->allocGen;                                   // a captured graph holds the old addresses
@@ -241,7 +242,15 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
         h->kpCap = g.maxQuotaSum + 4 * g.nlevels;
         h->maxAlive = 0;
         for (int l = 0; l < g.nlevels; ++l) h->maxAlive = std::max(h->maxAlive, std::max(g.lv[l].quota + 3, 4 * g.lv[l].nIni));
-        if (h->maxAlive > 2048) h->hostQuadtree = true;           // beyond the LDS capacity of k_quadtree
+        if (h->maxAlive > kQtMaxGlobal && !h->hostQuadtree) {     // beyond every GPU form of k_quadtree: said out loud, once per handle
+            h->hostQuadtree = true;
+            fprintf(stderr, "ssvio: a pyramid level asks for %d keypoints, more than the GPU quadtree holds (%d); DistributeOctTree "
+                            "runs in the library's host stage for this extractor (every other stage stays on the GPU)\n", h->maxAlive - 3, kQtMaxGlobal - 3);
+        }
+        if (h->maxAlive > kQtMaxLds && !h->hostQuadtree) {        // node arrays of the large-quota form, one block per (frame, level)
+            h->qtNodeStride = (quadtree_lds_bytes(h->maxAlive <= 8192 ? 8192 : kQtMaxGlobal) + 255) & ~(size_t)255;
+            SSVIO_HIP(hipMalloc(&h->d_qtNode, B * g.nlevels * h->qtNodeStride));
+        }
         SSVIO_HIP(hipMalloc(&h->d_pyr, B * g.frameBytes));
         SSVIO_HIP(hipMalloc(&h->d_blur, B * g.frameBytes));
         SSVIO_HIP(hipMemsetAsync(h->d_pyr, 0, B * g.frameBytes, h->stream));
@@ -378,6 +387,7 @@ static int orb_enqueue(ssvio_orb* h, int batch)
         a.rawPerFrame = g.slotsPerFrame; a.cellsPerFrame = g.cellsPerFrame;
         a.kval = h->d_kval; a.kord = h->d_kord; a.knode = h->d_knode;
         a.sel = h->d_sel; a.selCount = h->d_selCount; a.selPerFrame = h->kpCap; a.batch = batch;
+        a.nodeScratch = h->d_qtNode; a.nodeScratchStride = h->qtNodeStride;
         ProfScope p(h->prof, "k_quadtree", s);
         if (launch_quadtree(a, h->maxAlive, g.nlevels, batch, s)) { set_error("internal: quadtree capacity"); return SSVIO_ERR_INVALID; }
     }

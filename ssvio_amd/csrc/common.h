@@ -90,6 +90,7 @@ struct QtArgs {
     uint32_t* kval; uint32_t* kord; uint32_t* knode;     // per-key scratch, same indexing as raw
     uint2* sel; int* selCount; int selPerFrame;
     int batch;
+    unsigned char* nodeScratch; size_t nodeScratchStride;   // per-workgroup node arrays in HBM (quotas beyond the LDS forms), else null
 };
 
 static_assert(sizeof(QtArgs) <= 4096, "kernel arguments are passed by value: 4 KB limit");
@@ -174,6 +175,8 @@ void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, in
                  int iniTh, int minTh, uint2* raw, int* rawCount, int* cellIni, int batch, hipStream_t s);
 int  launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipStream_t s);
 void quadtree_prepare();
+size_t quadtree_lds_bytes(int maxa);   // bytes of node arrays for a capacity of maxa live nodes (LDS or HBM scratch)
+constexpr int kQtMaxLds = 2048, kQtMaxGlobal = 32768;
 void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int stripsPerFrame, int batch, hipStream_t s);
 // sel: per level lists {x | y<<16, level | resp<<8} at f*selPerFrame + selBase[l]; selCount[f][kMaxLevels]
 void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl,

@@ -42,12 +42,17 @@ __device__ __forceinline__ int qt_block_scan_excl(int v, int* wsum, int& total)
     return base + incl - v;
 }
 
-// MAXA = capacity of the live node list (>= quota + 3 and >= 4 * roots); IT = nodes per thread
-template <int MAXA>
+// MAXA = capacity of the live node list (>= quota + 3 and >= 4 * roots); IT = nodes per thread.
+// GLOBAL: the node arrays live in an HBM scratch block of this workgroup instead of LDS (quotas beyond 2045 keypoints per
+// level: 73 bytes per node do not fit 160 KB).  Same code: the arrays are only touched by this workgroup, whose waves share
+// the CU's vector L1, so a workgroup barrier orders the accesses exactly as it does for LDS; atomics go to L2.
+template <int MAXA, bool GLOBAL>
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
 {
     constexpr int IT = MAXA >= kQtThreads ? MAXA / kQtThreads : 1;     // nodes per thread (MAXA = 256: threads 256.. hold no node)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dynLds[];
+    __shared__ QtShared shGlobal;
+    unsigned char* smem = GLOBAL ? a.nodeScratch + (size_t)blockIdx.x * a.nodeScratchStride : dynLds;
     // ---- LDS carve (all offsets multiples of 16)
     unsigned long long* skeys = (unsigned long long*)smem;                 // MAXA   sort keys / final best
     uint2* rect[2]; int* cnt[2]; int* seq[2];
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
     int* remap = (int*)p; p += 4 * MAXA;
     int* cpre = (int*)p; p += 4 * MAXA;
     unsigned char* split = p; p += MAXA;
-    QtShared* sh = (QtShared*)p;
+    QtShared* sh = GLOBAL ? &shGlobal : (QtShared*)p;
 
     const int tid = threadIdx.x, lane = tid & 63;
     int frame, level;
@@ -355,9 +360,9 @@ void quadtree_prepare()
     (void)hipGetDevice(&dev);
     bool& attrSet = attrSetDev[dev & 63];
     if (!attrSet) {
-        (void)hipFuncSetAttribute((const void*)k_quadtree<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(256));
-        (void)hipFuncSetAttribute((const void*)k_quadtree<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(1024));
-        (void)hipFuncSetAttribute((const void*)k_quadtree<2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(2048));
+        (void)hipFuncSetAttribute((const void*)k_quadtree<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(256));
+        (void)hipFuncSetAttribute((const void*)k_quadtree<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(1024));
+        (void)hipFuncSetAttribute((const void*)k_quadtree<2048, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(2048));
         attrSet = true;
     }
 }
@@ -367,9 +372,11 @@ int launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipSt
     quadtree_prepare();
     // the smallest node capacity that holds quota + 3: 19 KB of LDS at 256 nodes (73 KB at 1024), so that the workgroups of
     // other kernels (k_fast, k_describe of the step in flight beside this one) still fit on the CU
-    if (maxAlive <= 256) hipLaunchKernelGGL(k_quadtree<256>, dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(256), s, a);
-    else if (maxAlive <= 1024) hipLaunchKernelGGL(k_quadtree<1024>, dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(1024), s, a);
-    else if (maxAlive <= 2048) hipLaunchKernelGGL(k_quadtree<2048>, dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(2048), s, a);
+    if (maxAlive <= 256) hipLaunchKernelGGL((k_quadtree<256, false>), dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(256), s, a);
+    else if (maxAlive <= 1024) hipLaunchKernelGGL((k_quadtree<1024, false>), dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(1024), s, a);
+    else if (maxAlive <= 2048) hipLaunchKernelGGL((k_quadtree<2048, false>), dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(2048), s, a);
+    else if (maxAlive <= 8192 && a.nodeScratch) hipLaunchKernelGGL((k_quadtree<8192, true>), dim3(nlevels * batch), dim3(kQtThreads), 0, s, a);
+    else if (maxAlive <= 32768 && a.nodeScratch) hipLaunchKernelGGL((k_quadtree<32768, true>), dim3(nlevels * batch), dim3(kQtThreads), 0, s, a);
     else return -1;
     return 0;
 }

@@ -221,8 +221,9 @@ def test_gpu_quadtree_dense_and_large_quotas(mods, kind, w, h, nf):
     g.close()
 
 
-def test_host_quadtree_mode_and_oversize_quota_fallback(mods, monkeypatch):
-    """SSVIO_QUADTREE=host and quotas beyond the GPU kernel's capacity (> 2045 per level) use the host stage; same results"""
+def test_host_quadtree_mode_and_oversize_quotas(mods, monkeypatch, capfd):
+    """SSVIO_QUADTREE=host selects the library's host stage; quotas beyond the LDS forms (> 2045 per level) run the GPU
+    quadtree with its node arrays in HBM (8192 / 32768 nodes); only beyond 32765 per level the host stage takes over, and says so"""
     S, synth, O = mods
     img = synth.texture(808, 480, 640)
     monkeypatch.setenv("SSVIO_QUADTREE", "host")
@@ -232,7 +233,16 @@ def test_host_quadtree_mode_and_oversize_quota_fallback(mods, monkeypatch):
     g.close()
     monkeypatch.delenv("SSVIO_QUADTREE")
     noise = (synth.Rng(9).bytes(640 * 480).reshape(480, 640) // 2 + img // 2).astype(np.uint8)
-    g = S.ORBextractor(12000, 1.2, 8, 20, 7); c = O.Extractor(12000, 1.2, 8, 20, 7)
+    for nf, nl in ((12000, 8), (40000, 8), (9000, 1), (30000, 2)):           # level quotas 2606, 8686, 9000, 16363: HBM node arrays
+        g = S.ORBextractor(nf, 1.2, nl, 20, 7); c = O.Extractor(nf, 1.2, nl, 20, 7)
+        capfd.readouterr()
+        kps, desc = g.Extract(noise)
+        assert "host stage" not in capfd.readouterr().err
+        _cmp_frame(O, g, c, noise, kps, desc)
+        assert len(kps) > 3000
+        g.close()
+    g = S.ORBextractor(160000, 1.2, 8, 20, 7); c = O.Extractor(160000, 1.2, 8, 20, 7)   # 34 745 at level 0
     kps, desc = g.Extract(noise)
+    assert "host stage" in capfd.readouterr().err
     _cmp_frame(O, g, c, noise, kps, desc)
     g.close()
