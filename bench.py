@@ -335,7 +335,7 @@ def main():
         m.set_stream(e.get_stream())
     mode = {"bf": L.MODE_BRUTEFORCE, "ratio": L.MODE_KNN2_RATIO, "crosscheck": L.MODE_CROSSCHECK, "dbow": -1}[args.match_mode]
     voc = None
-    if args.match_mode == "dbow" or not args.no_next_rows:
+    if args.match_mode == "dbow" or (rank == 0 and not args.no_next_rows):
         par, vdesc, vw = synth.vocabulary_tables_full(7, 10, 6)           # ORBvoc's shape: k = 10, L = 6, 1 111 111 nodes
         voc = ssvio_amd.Vocabulary(10, 6, par, vdesc, vw)
         for m in fms:
@@ -460,7 +460,7 @@ def main():
         valu = None
 
     trace('kernel table done')
-    nxt = None if args.no_next_rows else next_rows(exs[0], fms[0], d_frames, B, W, H, pairs, dev)
+    nxt = None if (args.no_next_rows or rank != 0) else next_rows(exs[0], fms[0], d_frames, B, W, H, pairs, dev)   # no collective inside: rank 0 only
     bm = None if args.no_batched_matching else batched_matching(rank, world, dev, dist)
     if rank == 0:
         out = {
