@@ -856,13 +856,15 @@ static int mt_check(ssvio_matcher* m) { if (!m) { set_error("null matcher handle
 // choose how many pieces the train set is cut into so that the launch has >= ~2048 workgroups (two per SIMD)
 static void pick_chunks(int maxQ, int maxT, int npairs, int& nChunks, int& chunkRows)
 {
-    const int R = maxQ > 2048 ? 4 : maxQ > 512 ? 2 : 1;
+    static const int forcedRows = [] { const char* e = getenv("SSVIO_MATCH_CHUNKROWS"); return e ? atoi(e) : 0; }();   // tuning knob
+    const int R = knn2_queries_per_lane(maxQ);
     const long qBlocks = (long)((maxQ + 256 * R - 1) / (256 * R)) * npairs;
     long want = (2048 + qBlocks - 1) / qBlocks;
     const long maxChunks = std::max(1, (maxT + 127) / 128);
     want = std::min<long>(std::min<long>(want, maxChunks), 64);
     nChunks = (int)std::max<long>(want, 1);
     chunkRows = ((maxT + nChunks - 1) / nChunks + 127) / 128 * 128;
+    if (forcedRows >= 128) chunkRows = forcedRows / 128 * 128;
     nChunks = std::max(1, (maxT + chunkRows - 1) / chunkRows);
 }
 

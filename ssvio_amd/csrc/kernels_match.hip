@@ -8,6 +8,7 @@
 // src/FeatureMatching.cpp:85-102,211-228 with lowest-index ties.  No MFMA: the path is
 // integer xor/popcount, VALU-bound.
 #include "match.h"
+#include <cstdlib>
 
 namespace ssvio {
 
@@ -110,20 +111,21 @@ __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
     }
 }
 
+// R = 4 keeps LDS reads at a quarter of the VALU time; small query sets use fewer so that more workgroups exist
+int knn2_queries_per_lane(int maxQ)
+{
+    static const int forced = [] { const char* e = getenv("SSVIO_MATCH_R"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return maxQ > 2048 ? 4 : maxQ > 512 ? 2 : 1;
+}
+
 void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s)
 {
-    // R = 4 keeps LDS reads at a quarter of the VALU time; small query sets use R = 1 so that
-    // more workgroups exist.
-    if (maxQ > 2048) {
-        dim3 grid((maxQ + 1023) / 1024, a.nChunks, npairs);
-        hipLaunchKernelGGL(k_hamming_knn2<4>, grid, dim3(256), 0, s, a);
-    } else if (maxQ > 512) {
-        dim3 grid((maxQ + 511) / 512, a.nChunks, npairs);
-        hipLaunchKernelGGL(k_hamming_knn2<2>, grid, dim3(256), 0, s, a);
-    } else {
-        dim3 grid((maxQ + 255) / 256, a.nChunks, npairs);
-        hipLaunchKernelGGL(k_hamming_knn2<1>, grid, dim3(256), 0, s, a);
-    }
+    const int R = knn2_queries_per_lane(maxQ);
+    dim3 grid((maxQ + 256 * R - 1) / (256 * R), a.nChunks, npairs);
+    if (R == 4) hipLaunchKernelGGL(k_hamming_knn2<4>, grid, dim3(256), 0, s, a);
+    else if (R == 2) hipLaunchKernelGGL(k_hamming_knn2<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_hamming_knn2<1>, grid, dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------

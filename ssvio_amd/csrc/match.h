@@ -104,6 +104,7 @@ void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, 
                   ssvio_dmatch* out, int* nout, hipStream_t s);
 
 void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);
+int  knn2_queries_per_lane(int maxQ);       // R of k_hamming_knn2<R> for this many query rows (tuning knob: SSVIO_MATCH_R)
 void launch_finalize(const FinalizeArgs& a, int npairs, int maxQ, int maxT, hipStream_t s);
 
 #if defined(__HIPCC__)
