@@ -216,7 +216,7 @@ class Extractor:
 
     def extract(self, gray):
         gray = _u8(gray); h, w = gray.shape
-        cap = self.nfeatures + 8 * self.nlevels + 64
+        cap = self.nfeatures + 40 * self.nlevels + 64      # a level's first quadtree round yields up to 4 nodes per root whatever its quota
         kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
         n = lib().orc_extract(self._h, _p(gray), w, h, gray.strides[0], _p(kps), _p(desc), cap)
         if n < 0:
@@ -225,7 +225,7 @@ class Extractor:
 
     def extract_rgb(self, rgb):
         rgb = _u8(rgb); h, w, _ = rgb.shape
-        cap = self.nfeatures + 8 * self.nlevels + 64
+        cap = self.nfeatures + 40 * self.nlevels + 64      # a level's first quadtree round yields up to 4 nodes per root whatever its quota
         kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
         n = lib().orc_extract_rgb(self._h, _p(rgb), w, h, rgb.strides[0], _p(kps), _p(desc), cap)
         if n < 0:

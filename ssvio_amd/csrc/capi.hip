@@ -239,7 +239,7 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
         h->d_tabs = tabs;
         const PyramidGeom& g = h->geom;
         const size_t B = (size_t)batch;
-        h->kpCap = g.maxQuotaSum + 4 * g.nlevels;
+        h->kpCap = g.maxQuotaSum;                                  // sum of the levels' capacities
         h->maxAlive = 0;
         for (int l = 0; l < g.nlevels; ++l) h->maxAlive = std::max(h->maxAlive, std::max(g.lv[l].quota + 3, 4 * g.lv[l].nIni));
         if (h->maxAlive > kQtMaxGlobal && !h->hostQuadtree) {     // beyond every GPU form of k_quadtree: said out loud, once per handle
@@ -339,7 +339,7 @@ static int orb_host_quadtree(ssvio_orb* h, int batch)
         const LevelGeom& G = g.lv[l];
         std::vector<int> sel;
         if (distribute_octtree(xs.data(), ys.data(), rs.data(), n, kMinBorder, G.maxBX, kMinBorder, G.maxBY, G.quota, sel)) { fail.store(1); return; }
-        if ((int)sel.size() > G.quota + 4) { fail.store(2); return; }
+        if ((int)sel.size() > level_sel_cap(G.quota)) { fail.store(2); return; }
         uint2* out = h->h_sel.data() + (size_t)f * h->kpCap + G.selBase;
         for (size_t i = 0; i < sel.size(); ++i) {
             const uint32_t e = c[sel[i]];
@@ -524,8 +524,8 @@ int ssvio_orb_max_keypoints(ssvio_orb* h)
 {
     if (orb_check(h)) return SSVIO_ERR_INVALID;
     int s = 0;
-    for (int i = 0; i < h->tab.nlevels; ++i) s += h->tab.quota[i];
-    return s + 4 * h->tab.nlevels;
+    for (int i = 0; i < h->tab.nlevels; ++i) s += level_sel_cap(h->tab.quota[i]);
+    return s;
 }
 
 int ssvio_orb_level_geometry(ssvio_orb* h, int width, int height, int level, int32_t* lw, int32_t* lh,

@@ -16,6 +16,10 @@ constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE, src/Feature.cpp:13
 constexpr int kMinBorder = 16;     // EDGE_THRESHOLD - 3, src/Feature.cpp:835
 constexpr int kPadX = 4;          // reflect-101 columns kept on both sides of every level row (for k_blur)
 constexpr int kMaxRoots = 8;       // quadtree roots per level = round(width / height) of the tested region (src/Feature.cpp:574)
+// Keypoints one level can deliver: the quadtree stops at >= quota nodes and a split adds at most 3 (quota + 3), but its
+// FIRST round splits every root whatever the quota (src/Feature.cpp:621-703: the size test follows the round), so a
+// level with a tiny quota can still end with 4 nodes per root.
+constexpr int level_sel_cap(int quota) { return quota + 4 > 4 * kMaxRoots ? quota + 4 : 4 * kMaxRoots; }
 constexpr int kMaxCellDim = 64;    // interior of a FAST cell window never exceeds 59 px (see geometry.cpp)
 
 void set_error(const char* fmt, ...);
@@ -57,7 +61,7 @@ struct PyramidGeom {
     size_t slotsPerFrame = 0;
     int blurStripsPerFrame = 0;
     int fastTilesPerFrame = 0, fastTilesPerFrameT = 0;
-    int maxQuotaSum = 0;
+    int maxQuotaSum = 0;      // sum of level_sel_cap(quota): keypoint slots per frame
 };
 
 // parameters handed to kernels by value: one record per level (a wave-uniform level index turns

@@ -86,7 +86,7 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
         L.cellBase = cell; cell += L.nCols * L.nRows;
         L.slotCap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);        // NMS leaves no two 8-adjacent maxima
         L.slotBase = slot; slot += (size_t)L.slotCap * L.nCols * L.nRows;
-        L.selBase = g.maxQuotaSum + 4 * l;
+        L.selBase = g.maxQuotaSum;                                      // running sum of level_sel_cap
         L.nIni = nIni; L.hX = fw / nIni;                                 // :576
         for (int i = 0; i <= nIni; ++i) L.rootX[i] = (int)(L.hX * (float)i);   // :585-586
         L.quota = t.quota[l]; L.scale = t.scale[l]; L.kpSize = (int)(kHalfPatch * t.scale[l]);   // src/Feature.cpp:900
@@ -102,7 +102,7 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
         L.fastTileBase = ftiles; ftiles += L.fastTilesX * L.fastTilesY;
         L.fastTilesYT = (L.h + 63) / 64;
         L.fastTileBaseT = ftilesT; ftilesT += L.fastTilesX * L.fastTilesYT;
-        g.maxQuotaSum += L.quota;
+        g.maxQuotaSum += level_sel_cap(L.quota);
     }
     g.frameBytes = off + 256;
     g.cellsPerFrame = cell; g.slotsPerFrame = slot; g.blurStripsPerFrame = tiles; g.fastTilesPerFrame = ftiles; g.fastTilesPerFrameT = ftilesT;

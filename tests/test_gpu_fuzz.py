@@ -22,7 +22,10 @@ def _cases(n, seed):
 
 
 @pytest.mark.parametrize("w,h,sf,nl,nf,ini,mn,seed", _cases(24, 20261110) + [(880, 130, 1.2, 3, 600, 20, 7, 5), (900, 100, 1.2, 2, 300, 20, 7, 6),
-                                                          (130, 420, 1.2, 2, 300, 20, 7, 7)])
+                                                          (130, 420, 1.2, 2, 300, 20, 7, 7),
+                                                          # tiny quotas: the first quadtree round yields 4 nodes per root whatever the quota
+                                                          (640, 260, 1.2, 8, 12, 20, 7, 8), (640, 200, 1.2, 6, 5, 20, 7, 9), (640, 480, 1.2, 8, 3, 20, 7, 10),
+                                                          (800, 150, 1.2, 4, 1, 20, 7, 11)])
 def test_random_configuration_equals_oracle(w, h, sf, nl, nf, ini, mn, seed):
     import ssvio_amd as S
     from ssvio_amd import synth

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st, HealthCheck
 
-CFG = dict(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+CFG = dict(max_examples=60, deadline=None, derandomize=True, database=None,      # the same examples on every run
+            suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 
 
 @settings(**CFG)
@@ -20,7 +21,8 @@ def test_host_quadtree_equals_oracle_on_random_point_sets(oracle, seed, n, N, w,
     want, _ = oracle.distribute_octtree(xs, ys, resp, 0, w, 0, h, N)
     got = ssvio_amd.distribute_octtree(xs, ys, resp, 0, w, 0, h, N)
     assert np.array_equal(got, want)
-    assert len(set(got.tolist())) == len(got) and len(got) <= min(len(flat), N + 3)
+    # the first round splits every root whatever N is (the size test follows the round): up to 4 nodes per root
+    assert len(set(got.tolist())) == len(got) and len(got) <= min(len(flat), max(N + 3, 4 * round(w / h)))
 
 
 @settings(**CFG)
