@@ -2,10 +2,12 @@
 odd places, scale factors on both sides of the streaming resize kernel's range, pyramid depths, quotas and FAST
 thresholds.  Bit-exact end to end against the oracle, like test_gpu_extract.py; configurations whose upper levels
 are too small for a 30-px cell must be refused on both sides."""
+import os
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+EXTRA = int(os.environ.get("SSVIO_FUZZ_EXTRA", "0"))          # more random cases for a one-off soak (seeded by the count)
 
 
 def _cases(n, seed):
@@ -21,7 +23,7 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("w,h,sf,nl,nf,ini,mn,seed", _cases(24, 20261110) + [(880, 130, 1.2, 3, 600, 20, 7, 5), (900, 100, 1.2, 2, 300, 20, 7, 6),
+@pytest.mark.parametrize("w,h,sf,nl,nf,ini,mn,seed", _cases(24, 20261110) + _cases(EXTRA, 777 + EXTRA) + [(880, 130, 1.2, 3, 600, 20, 7, 5), (900, 100, 1.2, 2, 300, 20, 7, 6),
                                                           (130, 420, 1.2, 2, 300, 20, 7, 7),
                                                           # tiny quotas: the first quadtree round yields 4 nodes per root whatever the quota
                                                           (640, 260, 1.2, 8, 12, 20, 7, 8), (640, 200, 1.2, 6, 5, 20, 7, 9), (640, 480, 1.2, 8, 3, 20, 7, 10),
@@ -65,7 +67,7 @@ def _match_cases(n, seed):
     return [(int(rng.integers(1, 3000)), int(rng.integers(1, 3000)), int(rng.integers(0, 1 << 30))) for _ in range(n)]
 
 
-@pytest.mark.parametrize("nq,nt,seed", _match_cases(16, 99))
+@pytest.mark.parametrize("nq,nt,seed", _match_cases(16, 99) + _match_cases(EXTRA, 555 + EXTRA))
 def test_random_match_shapes_equal_oracle(nq, nt, seed):
     import ssvio_amd as S
     from ssvio_amd import synth
@@ -114,3 +116,48 @@ def test_ragged_batches_equal_oracle(seed, mode):
         want = ref(sets[a], sets[c])
         assert n[p] == len(want) and np.array_equal(out[p, :n[p]].view(np.uint8), want.view(np.uint8)), (p, counts[a], counts[c])
     fm.close()
+
+
+def _dbow_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        k = int(rng.choice([2, 3, 5, 10, 17, 40])); L = int(rng.integers(1, 6 if k <= 10 else 3))
+        out.append((k, L, int(rng.integers(0, L + 3)), float(rng.choice([0.0, 0.2, 0.6])), int(rng.integers(1, 2500)), int(rng.integers(1, 2500)),
+                    int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("k,L,levelsup,early,nq,nt,seed", _dbow_cases(12, 4242) + _dbow_cases(EXTRA // 3, 4243 + EXTRA))
+def test_random_dbow_configurations_equal_oracle(k, L, levelsup, early, nq, nt, seed):
+    import ssvio_amd as S
+    from ssvio_amd import synth
+    from oracle import oracle as O
+    par, desc, w = synth.vocabulary_tables(seed % 100000, k, L, early_leaf_p=early, stop_p=[0.0, 0.05, 0.5][seed % 3])
+    if len(par) > 200000:
+        pytest.skip("vocabulary too large for the python generator")
+    v = S.Vocabulary(k, L, par, desc, w); ov = O.Vocabulary(k, L, par, desc, w, v.word)
+    rng = np.random.default_rng(seed)
+    t = synth.descriptors_near_leaves(seed + 1, nt, par, desc, 0.03)
+    q = t[rng.integers(0, nt, nq)] ^ np.packbits(rng.random((nq, 256)) < 0.03, axis=1, bitorder="little")
+    th, ratio = [(50, 0.6), (30, 0.8), (100, 0.99)][seed % 3]
+    fm = S.FeatureMatching(v, {"Threshold": th, "NNRatio": ratio})
+    word, node, weight = fm.ComputeBoWVector(q, levelsup)[2]
+    rw, rn, rwt = ov.transform(q, levelsup)
+    assert np.array_equal(word, rw) and np.array_equal(node, rn) and np.array_equal(weight, rwt)
+    ok, m = fm.MatchByDBoW(q, t, levelsup=levelsup)
+    want = O.match_dbow(ov, q, t, th, ratio, levelsup)
+    assert np.array_equal(m.view(np.uint8), want.view(np.uint8))
+    # behind the matcher, on the same match list with made-up keypoints and depth
+    kq = np.zeros(nq, S.KP_DTYPE); kt = np.zeros(nt, S.KP_DTYPE)
+    kq["x"] = rng.random(nq) * 319; kq["y"] = rng.random(nq) * 239; kt["x"] = rng.random(nt) * 319; kt["y"] = rng.random(nt) * 239
+    dq, dt = synth.depth_image(seed % 1000, 240, 320, hole_p=0.3), synth.depth_image(seed % 1000 + 1, 240, 320, hole_p=0.3)
+    cam = O.camera(160.5912, 120.4792, 253.0589, 254.1649, 10.0)
+    got = fm.AssembleCorrespondences(m, kt, dt, kq, dq, cam)
+    ref = O.assemble_correspondences(m, kt, dt, kq, dq, cam)
+    for key in ref:
+        assert np.array_equal(np.ascontiguousarray(got[key]).view(np.uint8), np.ascontiguousarray(ref[key]).view(np.uint8)), key
+    last = np.zeros(min(nq, 700), S.DM_DTYPE); last["queryIdx"] = rng.integers(0, nt, len(last)); last["trainIdx"] = rng.integers(0, nt, len(last))
+    assert np.array_equal(fm.TrackMapPoints(last, m).view(np.uint8), O.track_map_points(last, m).view(np.uint8))
+    assert np.array_equal(fm.InMatchVec(m, nq), O.in_match_vec(m, nq))
+    fm.close(); v.close()
