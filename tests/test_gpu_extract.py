@@ -246,3 +246,33 @@ def test_host_quadtree_mode_and_oversize_quotas(mods, monkeypatch, capfd):
     assert "host stage" in capfd.readouterr().err
     _cmp_frame(O, g, c, noise, kps, desc)
     g.close()
+
+
+def test_two_threads_with_their_own_handles(mods):
+    """handles are independent (SURVEY.md §8b threading): two host threads, each with its own extractor + matcher, run
+    concurrently and both get the oracle's answers"""
+    import threading
+    S, synth, O = mods
+    imgs = [synth.texture(900 + i, 240, 320) for i in range(4)]
+    c = O.Extractor(800, 1.2, 8, 20, 7)
+    ref = [c.extract(im) for im in imgs]
+    refm = O.match_bruteforce(ref[1][1], ref[0][1])
+    errs = []
+
+    def worker(tid):
+        try:
+            g = S.ORBextractor(800, 1.2, 8, 20, 7); fm = S.FeatureMatching(None, {})
+            for it in range(12):
+                i = (tid + it) % 4
+                k, d = g.Extract(imgs[i])
+                assert np.array_equal(k.view(np.uint8), ref[i][0].view(np.uint8)) and np.array_equal(d, ref[i][1])
+                ok, m = fm.MatchByBruteForce(ref[1][1], ref[0][1])
+                assert np.array_equal(m.view(np.uint8), refm.view(np.uint8))
+            g.close(); fm.close()
+        except Exception as e:                                   # noqa: BLE001 -- reported by the main thread
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs, errs
