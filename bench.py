@@ -50,6 +50,22 @@ def pmc_traffic(kernel):
     return None
 
 
+STATS_FILE = os.path.join(ROOT, "profiles", "r1", "r1_final_kernel_stats.csv")
+
+
+def rocprof_avg_us(kernel):
+    """average duration of `kernel` in the committed `rocprofv3 --kernel-trace --stats` summary of this same command
+    (tools/gpu_profile.sh), for comparison with the live hipEvent figures; None when the file is absent"""
+    import csv
+    try:
+        for r in csv.DictReader(open(STATS_FILE)):
+            if r["Name"].replace("void ", "").startswith("ssvio::" + kernel + "<") or r["Name"].replace("void ", "").startswith("ssvio::" + kernel + "("):
+                return round(float(r["AverageNs"]) / 1e3, 2)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def level_pixels(ex, w, h):
     return [ex.level_geometry(w, h, l)["w"] * ex.level_geometry(w, h, l)["h"] for l in range(ex.nlevels)]
 
@@ -446,6 +462,9 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom) if (B, W, H, args.features) == (64, 640, 480, 1000) else None,
             "traffic_source": "profiles/r1/r1_final_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, default batch)",
             "avg_launch_us": round(dom_avg_s * 1e6, 2), "alg_bytes_per_launch": int(dom_bytes),
+            "avg_launch_note": "hipEvent pair around the kernel on its stream inside the timed region: with several steps in flight it includes "
+                               "the wait for CUs held by the other steps' kernels; exclusive_* is the same kernel with one step in flight",
+            "rocprof_avg_launch_us": rocprof_avg_us(dom) if (B, W, H, args.features) == (64, 640, 480, 1000) else None,
             "exclusive_avg_launch_us": round(times[dom][0] * 1e3 / times[dom][1], 2),
             "exclusive_frac": round(dom_bytes / (times[dom][0] * 1e-3 / times[dom][1]) / 1e9 / HBM_PEAK_GBS, 5)}
     # the matcher is VALU-bound (xor+popcount), not HBM-bound: report its VALU fraction beside it
