@@ -66,6 +66,24 @@ def rocprof_avg_us(kernel):
     return None
 
 
+SQ_FILE = os.path.join(ROOT, "profiles", "r1", "r1_final_pmc_sq.txt")
+
+
+def valu_busy(kernel, kernel_us):
+    """share of the chip's VALU issue capacity the kernel uses: SQ_ACTIVE_INST_VALU (cycles a SIMD spends issuing VALU, summed)
+    x 4 / (1024 SIMDs x kernel cycles at 2.4 GHz), counter from the committed rocprofv3 --pmc pass (tools/gpu_pmc.sh); None if absent"""
+    import re
+    try:
+        for line in open(SQ_FILE):
+            if line.startswith(kernel + "<") or line.startswith(kernel + " "):
+                m = re.search(r"SQ_ACTIVE_INST_VALU=([0-9.e+]+)", line)
+                if m and kernel_us > 0:
+                    return round(float(m.group(1)) * 4 / (1024 * kernel_us * 2400.0), 3)
+    except OSError:
+        pass
+    return None
+
+
 def level_pixels(ex, w, h):
     return [ex.level_geometry(w, h, l)["w"] * ex.level_geometry(w, h, l)["h"] for l in range(ex.nlevels)]
 
@@ -465,6 +483,8 @@ def main():
             "avg_launch_note": "hipEvent pair around the kernel on its stream inside the timed region: with several steps in flight it includes "
                                "the wait for CUs held by the other steps' kernels; exclusive_* is the same kernel with one step in flight",
             "rocprof_avg_launch_us": rocprof_avg_us(dom) if (B, W, H, args.features) == (64, 640, 480, 1000) else None,
+            "valu_busy": valu_busy(dom, times[dom][0] * 1e3 / times[dom][1]) if (B, W, H, args.features) == (64, 640, 480, 1000) else None,
+            "binds": "VALU issue, not HBM: the path is integer byte work with ~60 lane-instructions per pixel (DESIGN.md section 3); the HBM fraction is reported because the contract asks for it",
             "exclusive_avg_launch_us": round(times[dom][0] * 1e3 / times[dom][1], 2),
             "exclusive_frac": round(dom_bytes / (times[dom][0] * 1e-3 / times[dom][1]) / 1e9 / HBM_PEAK_GBS, 5)}
     # the matcher is VALU-bound (xor+popcount), not HBM-bound: report its VALU fraction beside it
