@@ -2,6 +2,7 @@
 // feature quotas, FAST cell grid, bilinear-resize coefficient tables, and the
 // quadtree keypoint distribution.  Product code (no dependency on oracle/).
 #include "common.h"
+#include <cstdlib>
 #include <cmath>
 #include <cstdarg>
 #include <algorithm>
@@ -93,7 +94,8 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
         // k_blur strips: 120 output px wide (32 lanes x 4 px, first/last lane are halo), 7*iters-6 rows tall
         L.blurStripsX = (L.w + 119) / 120;
         {
-            const int nsY = (L.h + 56) / 57, rows = (L.h + nsY - 1) / nsY;
+            static const int target = [] { const char* e = getenv("SSVIO_BLUR_ROWS"); const int v = e ? atoi(e) : 0; return v >= 8 ? v : 29; }();   // rows per strip (SSVIO_BLUR_ROWS: tuning knob; 57 -> 29 rows: 79 -> 62 us per 64 VGA frames)
+            const int nsY = (L.h + target - 1) / target, rows = (L.h + nsY - 1) / nsY;
             L.blurIters = (rows + 6 + 6) / 7;
             L.blurStripsY = (L.h + (7 * L.blurIters - 6) - 1) / (7 * L.blurIters - 6);
         }
