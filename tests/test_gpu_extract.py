@@ -276,3 +276,20 @@ def test_two_threads_with_their_own_handles(mods):
     for t in ts: t.start()
     for t in ts: t.join()
     assert not errs, errs
+
+
+def test_4k_frame_and_size_limit(mods):
+    """the largest supported level is 4128 px on a side (12-bit candidate coordinates); a 3840x2160 frame is inside, wider
+    frames are refused with SSVIO_ERR_GEOMETRY instead of wrapping"""
+    S, synth, O = mods
+    rng = synth.Rng(4)
+    base = synth.texture(31, 540, 960)
+    img = np.ascontiguousarray(np.kron(base, np.ones((4, 4), np.uint8)) // 2 + rng.bytes(2160 * 3840).reshape(2160, 3840) // 2).astype(np.uint8)
+    g = S.ORBextractor(5000, 1.2, 8, 20, 7); c = O.Extractor(5000, 1.2, 8, 20, 7)
+    kps, desc = g.Extract(img)
+    _cmp_frame(O, g, c, img, kps, desc)
+    assert len(kps) > 4000
+    with pytest.raises(S.SsvioError) as e:
+        g.Extract(np.zeros((200, 4200), np.uint8))
+    assert e.value.code == -4
+    g.close()
