@@ -293,3 +293,30 @@ def test_4k_frame_and_size_limit(mods):
         g.Extract(np.zeros((200, 4200), np.uint8))
     assert e.value.code == -4
     g.close()
+
+
+def test_hipgraph_replay_gives_the_same_results():
+    """SSVIO_GRAPH=1 (read once per process, hence the child process): captured launch sequence, several batch sizes and a
+    size change on one handle, against the oracle"""
+    import os, subprocess, sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import ssvio_amd as S
+from ssvio_amd import synth
+from oracle import oracle as O
+g = S.ORBextractor(700, 1.2, 8, 20, 7); c = O.Extractor(700, 1.2, 8, 20, 7)
+for (h, w, reps) in ((240, 320, 3), (300, 400, 2), (240, 320, 2)):
+    imgs = [synth.texture(50 + i, h, w) for i in range(3)]
+    for r in range(reps):
+        for im in imgs:
+            k, d = g.Extract(im); rk, rd = c.extract(im)
+            assert np.array_equal(k.view(np.uint8), rk.view(np.uint8)) and np.array_equal(d, rd)
+    ks, ds, ns = g.extract_batch(np.stack(imgs))
+    for f, im in enumerate(imgs):
+        rk, rd = c.extract(im)
+        assert ns[f] == len(rk) and np.array_equal(ks[f, :ns[f]].view(np.uint8), rk.view(np.uint8))
+print("graph ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSVIO_GRAPH="1"), capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0 and "graph ok" in r.stdout, r.stderr[-2000:]
