@@ -1,7 +1,7 @@
-// capi.hip -- the C ABI of include/ssvio_gpu.h: handles, device memory, streams and
-// the per-batch orchestration of the gfx950 kernels.
-#include "common.h"
-#include "match.h"
+// capi.hip -- the C ABI of include/ssvio_gpu.h, part 1: library entry points, the profiler, and the extractor handle
+// (device memory, streams, per-batch orchestration of the extraction kernels).  The matcher lives in capi_match.hip,
+// MatchByDBoW in capi_bow.hip, the steps behind the matcher in capi_frame.hip.
+#include "capi_internal.h"
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -117,7 +117,7 @@ static int host_threads()
     return (int)std::min<unsigned>(hc ? hc : 4, 16);
 }
 
-static int pick_device(int device)
+int pick_device(int device)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -128,8 +128,20 @@ static int pick_device(int device)
     return SSVIO_OK;
 }
 
-template <typename T> static void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
-template <typename T> static void hfree(T*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } }
+
+int prof_out(KernelProfiler& p, const char** names, double* total_ms, int32_t* launches, int cap, int* count)
+{
+    if (!count) { set_error("null count"); return SSVIO_ERR_INVALID; }
+    p.resolve();
+    const int n = (int)p.stats.size();
+    *count = n;
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (names) names[i] = p.stats[i].name;
+        if (total_ms) total_ms[i] = p.stats[i].ms;
+        if (launches) launches[i] = p.stats[i].launches;
+    }
+    return SSVIO_OK;
+}
 
 }  // namespace ssvio
 
@@ -755,20 +767,6 @@ int ssvio_orb_set_profiling(ssvio_orb* h, int enable)
     return SSVIO_OK;
 }
 
-static int prof_out(KernelProfiler& p, const char** names, double* total_ms, int32_t* launches, int cap, int* count)
-{
-    if (!count) { set_error("null count"); return SSVIO_ERR_INVALID; }
-    p.resolve();
-    const int n = (int)p.stats.size();
-    *count = n;
-    for (int i = 0; i < n && i < cap; ++i) {
-        if (names) names[i] = p.stats[i].name;
-        if (total_ms) total_ms[i] = p.stats[i].ms;
-        if (launches) launches[i] = p.stats[i].launches;
-    }
-    return SSVIO_OK;
-}
-
 int ssvio_orb_kernel_times(ssvio_orb* h, const char** names, double* total_ms, int32_t* launches, int cap, int* count)
 {
     if (orb_check(h)) return SSVIO_ERR_INVALID;
@@ -795,847 +793,3 @@ int ssvio_orb_set_stream(ssvio_orb* h, void* hip_stream)
 }
 
 }  // extern "C"
-
-// =====================================================================================
-struct ssvio_matcher {
-    int device = 0;
-    int threshold = 50; float nnRatio = 0.6f;
-    hipStream_t own = nullptr, stream = nullptr;
-    uint8_t* d_q = nullptr; size_t qRows = 0;
-    uint8_t* d_t = nullptr; size_t tRows = 0;
-    int* d_counts2 = nullptr;            // {nq, nt} of the single-pair entry points
-    uint2* d_partial = nullptr; size_t partialCap = 0;
-    uint2* d_partialRev = nullptr; size_t partialRevCap = 0;
-    ssvio_dmatch* d_out = nullptr; size_t outCap = 0;
-    int32_t* d_raw = nullptr; size_t rawCap = 0;
-    int* d_nout = nullptr; size_t noutCap = 0;
-    int* d_pairs = nullptr; size_t pairsCap = 0;
-    double* d_p3d = nullptr; size_t p3dCap = 0; double* d_p2d = nullptr; size_t p2dCap = 0;     // MatchByProject inputs
-    ssvio_dmatch* d_cand = nullptr; size_t candCap = 0; int* d_keep = nullptr; size_t keepCap = 0;
-    // MatchByDBoW: per-feature transform results (query rows first, then train rows) and the grouped-match scratch
-    int32_t* d_bowWord = nullptr; size_t bowWordCap = 0; int32_t* d_bowNode = nullptr; size_t bowNodeCap = 0;
-    double* d_bowWeight = nullptr; size_t bowWeightCap = 0; int32_t* d_gnode = nullptr; size_t gnodeCap = 0;
-    int32_t* d_keepNode = nullptr; size_t keepNodeCap = 0;
-    int32_t* d_sortIdx = nullptr; size_t sortIdxCap = 0; int32_t* d_sortNode = nullptr; size_t sortNodeCap = 0;
-    int lastBowQ = 0, lastBowT = 0;
-    // behind the matcher (f2, f3)
-    uint8_t* d_frameIn = nullptr; size_t frameInCap = 0;      // uploaded matches / keypoints / depth of the host entry points
-    uint8_t* d_frameOut = nullptr; size_t frameOutCap = 0;    // assembled lists
-    uint32_t* d_table = nullptr; size_t tableCap = 0;
-    std::vector<uint8_t> stageQ, stageT;              // packed copies of strided descriptor rows
-    std::vector<int32_t> h_pairs;                     // what d_pairs holds (an unchanged pair list is not uploaded again)
-    KernelProfiler prof; std::string profOnly;
-    int lastPairs = 0, lastMaxRows = 0;
-};
-
-template <typename T> static int grow(T*& p, size_t& cap, size_t need, hipStream_t s)
-{
-    if (need <= cap) return SSVIO_OK;
-    SSVIO_HIP(hipStreamSynchronize(s));
-    dfree(p);
-    need += need / 4;
-    SSVIO_HIP(hipMalloc(&p, need * sizeof(T)));
-    cap = need;
-    return SSVIO_OK;
-}
-
-// descriptor rows host -> device.  Continuous rows (the usual cv::Mat) are one copy; strided rows are packed on the
-// host first: a 2-D copy of 32-byte rows costs a transfer per row (18 ms for 1000 rows on this stack).
-static int upload_rows(uint8_t* dst, const uint8_t* src, int n, int stride, std::vector<uint8_t>& staging, hipStream_t s)
-{
-    if (n <= 0) return SSVIO_OK;
-    if (stride == 32) { SSVIO_HIP(hipMemcpyAsync(dst, src, (size_t)n * 32, hipMemcpyHostToDevice, s)); return SSVIO_OK; }
-    staging.resize((size_t)n * 32);
-    for (int i = 0; i < n; ++i) memcpy(staging.data() + (size_t)i * 32, src + (size_t)i * stride, 32);
-    SSVIO_HIP(hipMemcpyAsync(dst, staging.data(), (size_t)n * 32, hipMemcpyHostToDevice, s));
-    return SSVIO_OK;
-}
-
-static int mt_check(ssvio_matcher* m) { if (!m) { set_error("null matcher handle"); return SSVIO_ERR_INVALID; } return SSVIO_OK; }
-
-// choose how many pieces the train set is cut into so that the launch has >= ~2048 workgroups (two per SIMD)
-static void pick_chunks(int maxQ, int maxT, int npairs, int& nChunks, int& chunkRows)
-{
-    static const int forcedRows = [] { const char* e = getenv("SSVIO_MATCH_CHUNKROWS"); return e ? atoi(e) : 0; }();   // tuning knob
-    const int R = knn2_queries_per_lane(maxQ);
-    const long qBlocks = (long)((maxQ + 256 * R - 1) / (256 * R)) * npairs;
-    long want = (2048 + qBlocks - 1) / qBlocks;
-    const long maxChunks = std::max(1, (maxT + 127) / 128);
-    want = std::min<long>(std::min<long>(want, maxChunks), 64);
-    nChunks = (int)std::max<long>(want, 1);
-    chunkRows = ((maxT + nChunks - 1) / nChunks + 127) / 128 * 128;
-    if (forcedRows >= 128) chunkRows = forcedRows / 128 * 128;
-    nChunks = std::max(1, (maxT + chunkRows - 1) / chunkRows);
-}
-
-// the pair list of the batched entry points, on the device (an unchanged list is not uploaded again)
-static int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs)
-{
-    if (m->h_pairs.size() == (size_t)npairs * 2 && memcmp(m->h_pairs.data(), pairs, (size_t)npairs * 2 * sizeof(int32_t)) == 0) return SSVIO_OK;
-    int rc = grow(m->d_pairs, m->pairsCap, (size_t)npairs * 2, m->stream); if (rc) return rc;
-    SSVIO_HIP(hipStreamSynchronize(m->stream));    // earlier launches may still read the old list
-    m->h_pairs.assign(pairs, pairs + (size_t)npairs * 2);
-    SSVIO_HIP(hipMemcpyAsync(m->d_pairs, m->h_pairs.data(), (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    SSVIO_HIP(hipStreamSynchronize(m->stream));
-    return SSVIO_OK;
-}
-
-// shared driver: descriptors on the device; pairs == nullptr means the single pair (0,0)
-static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
-                     const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts,
-                     const int* d_pairs, int npairs, int maxQ, int maxT, int mode)
-{
-    hipStream_t s = m->stream;
-    const int maxRows = std::max(maxQ, maxT);
-    int nChunks, chunkRows;
-    pick_chunks(maxQ, maxT, npairs, nChunks, chunkRows);
-    int rc = grow(m->d_partial, m->partialCap, (size_t)npairs * nChunks * maxRows, s); if (rc) return rc;
-    rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
-    if (mode == 3) { rc = grow(m->d_raw, m->rawCap, (size_t)npairs * 3 * maxRows, s); if (rc) return rc; }
-    else { rc = grow(m->d_out, m->outCap, (size_t)npairs * maxRows, s); if (rc) return rc; }
-    MatchArgs a{};
-    a.qdesc = (const uint4*)d_qdesc; a.tdesc = (const uint4*)d_tdesc;
-    a.qSetStrideRows = qStrideRows; a.tSetStrideRows = tStrideRows;
-    a.qcounts = d_qcounts; a.tcounts = d_tcounts; a.pairs = d_pairs; a.swap = 0;
-    a.nChunks = nChunks; a.chunkRows = chunkRows; a.partial = m->d_partial; a.maxRows = maxRows;
-    {
-        ProfScope p(m->prof, "k_hamming_knn2", s);
-        launch_knn2(a, maxQ, npairs, s);
-    }
-    FinalizeArgs f{};
-    f.partial = m->d_partial; f.nChunks = nChunks; f.maxRows = maxRows;
-    f.qcounts = d_qcounts; f.tcounts = d_tcounts; f.pairs = d_pairs;
-    f.mode = mode; f.threshold = m->threshold; f.nnRatio = m->nnRatio;
-    f.out = m->d_out; f.nout = m->d_nout; f.raw = m->d_raw;
-    if (mode == SSVIO_MODE_CROSSCHECK) {
-        int nChunksR, chunkRowsR;
-        pick_chunks(maxT, maxQ, npairs, nChunksR, chunkRowsR);
-        rc = grow(m->d_partialRev, m->partialRevCap, (size_t)npairs * nChunksR * maxRows, s); if (rc) return rc;
-        MatchArgs r = a;
-        r.qdesc = (const uint4*)d_tdesc; r.tdesc = (const uint4*)d_qdesc;
-        r.qSetStrideRows = tStrideRows; r.tSetStrideRows = qStrideRows;
-        r.qcounts = d_tcounts; r.tcounts = d_qcounts; r.swap = 1;
-        r.nChunks = nChunksR; r.chunkRows = chunkRowsR; r.partial = m->d_partialRev;
-        {
-            ProfScope p(m->prof, "k_hamming_knn2", s);
-            launch_knn2(r, maxT, npairs, s);
-        }
-        f.partialRev = m->d_partialRev; f.nChunksRev = nChunksR;
-    }
-    {
-        ProfScope p(m->prof, "k_match_finalize", s);
-        launch_finalize(f, npairs, maxQ, maxT, s);
-    }
-    m->lastPairs = npairs; m->lastMaxRows = maxRows;
-    return SSVIO_OK;
-}
-
-// host-pointer single pair
-static int match_host(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, int mode,
-                      ssvio_dmatch* out, int cap, int* n, int32_t* idx, int32_t* d1, int32_t* d2)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    if (nq < 0 || nt < 0) { set_error("negative row count"); return SSVIO_ERR_INVALID; }
-    if (n) *n = 0;
-    if (!(nq > 0 && nt > 0)) return SSVIO_OK;                          // src/FeatureMatching.cpp:25-27
-    if (!q || !t) { set_error("null descriptor pointer"); return SSVIO_ERR_INVALID; }
-    if (qstride < 32 || tstride < 32) { set_error("descriptor stride < 32"); return SSVIO_ERR_INVALID; }
-    if (nt > (1 << 23) || nq > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
-    if (mode != 3 && cap < nq) { set_error("output capacity %d < %d query rows", cap, nq); return SSVIO_ERR_CAPACITY; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
-    int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
-    rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
-    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
-    rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
-    const int counts[2] = {nq, nt};
-    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipStreamSynchronize(s));                                // `counts` is a stack array
-    rc = match_run(m, m->d_q, 0, m->d_counts2, m->d_t, 0, m->d_counts2 + 1, nullptr, 1, nq, nt, mode);
-    if (rc) return rc;
-    const int maxRows = std::max(nq, nt);
-    if (mode == 3) {
-        std::vector<int32_t> raw((size_t)3 * maxRows);
-        SSVIO_HIP(hipMemcpyAsync(raw.data(), m->d_raw, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < nq; ++i) { if (idx) idx[i] = raw[i]; if (d1) d1[i] = raw[maxRows + i]; if (d2) d2[i] = raw[2 * (size_t)maxRows + i]; }
-    } else {
-        int cnt = 0;
-        SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipStreamSynchronize(s));
-        if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
-        if (n) *n = cnt;
-    }
-    m->prof.resolve();
-    return SSVIO_OK;
-}
-
-extern "C" {
-
-int ssvio_matcher_create(int threshold, float nn_ratio, int device, ssvio_matcher** out)
-{
-    if (!out) { set_error("null argument"); return SSVIO_ERR_INVALID; }
-    *out = nullptr;
-    const int rc = pick_device(device);
-    if (rc) return rc;
-    SSVIO_HIP(hipSetDevice(device));
-    ssvio_matcher* m = new ssvio_matcher();
-    m->device = device; m->threshold = threshold; m->nnRatio = nn_ratio;
-    if (hipStreamCreateWithFlags(&m->own, hipStreamNonBlocking) != hipSuccess || hipMalloc(&m->d_counts2, 2 * sizeof(int)) != hipSuccess) {
-        set_error("cannot create HIP stream / allocate"); delete m; return SSVIO_ERR_HIP;
-    }
-    m->stream = m->own;
-    *out = m;
-    return SSVIO_OK;
-}
-
-void ssvio_matcher_destroy(ssvio_matcher* m)
-{
-    if (!m) return;
-    (void)hipSetDevice(m->device);
-    (void)hipStreamSynchronize(m->stream);
-    m->prof.resolve(); m->prof.destroy();
-    dfree(m->d_q); dfree(m->d_t); dfree(m->d_counts2); dfree(m->d_partial); dfree(m->d_partialRev);
-    dfree(m->d_out); dfree(m->d_raw); dfree(m->d_nout); dfree(m->d_pairs);
-    dfree(m->d_p3d); dfree(m->d_p2d); dfree(m->d_cand); dfree(m->d_keep);
-    dfree(m->d_bowWord); dfree(m->d_bowNode); dfree(m->d_bowWeight); dfree(m->d_gnode); dfree(m->d_keepNode); dfree(m->d_sortIdx); dfree(m->d_sortNode);
-    dfree(m->d_frameIn); dfree(m->d_frameOut); dfree(m->d_table);
-    if (m->own) (void)hipStreamDestroy(m->own);
-    delete m;
-}
-
-int ssvio_matcher_set_stream(ssvio_matcher* m, void* hip_stream)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    SSVIO_HIP(hipSetDevice(m->device));
-    SSVIO_HIP(hipStreamSynchronize(m->stream));
-    m->stream = hip_stream ? (hipStream_t)hip_stream : m->own;
-    return SSVIO_OK;
-}
-
-int ssvio_matcher_profile_only(ssvio_matcher* m, const char* kernel)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    m->profOnly = kernel ? kernel : "";
-    m->prof.only = m->profOnly.empty() ? nullptr : m->profOnly.c_str();
-    return SSVIO_OK;
-}
-
-int ssvio_matcher_set_profiling(ssvio_matcher* m, int enable)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    SSVIO_HIP(hipSetDevice(m->device));
-    SSVIO_HIP(hipStreamSynchronize(m->stream));
-    m->prof.clear();
-    m->prof.enabled = enable != 0;
-    return SSVIO_OK;
-}
-
-int ssvio_matcher_kernel_times(ssvio_matcher* m, const char** names, double* total_ms, int32_t* launches, int cap, int* count)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    SSVIO_HIP(hipSetDevice(m->device));
-    SSVIO_HIP(hipStreamSynchronize(m->stream));
-    return prof_out(m->prof, names, total_ms, launches, cap, count);
-}
-
-int ssvio_match_bruteforce(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
-                           ssvio_dmatch* out, int cap, int* n)
-{ return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_BRUTEFORCE, out, cap, n, nullptr, nullptr, nullptr); }
-
-int ssvio_match_knn2_ratio(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
-                           ssvio_dmatch* out, int cap, int* n)
-{ return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_KNN2_RATIO, out, cap, n, nullptr, nullptr, nullptr); }
-
-int ssvio_match_crosscheck(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
-                           ssvio_dmatch* out, int cap, int* n)
-{ return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_CROSSCHECK, out, cap, n, nullptr, nullptr, nullptr); }
-
-int ssvio_match_knn2_raw(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
-                         int32_t* idx, int32_t* d1, int32_t* d2)
-{ return match_host(m, q, nq, qstride, t, nt, tstride, 3, nullptr, 0, nullptr, idx, d1, d2); }
-
-int ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, int nq, int qstride,
-                        const double* p2d, const uint8_t* t, int nt, int tstride, double radian,
-                        const double* K, const double* R, const double* tr, ssvio_dmatch* out, int cap, int* n)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    if (n) *n = 0;
-    if (nq < 0 || nt < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
-    if (nq == 0) return SSVIO_OK;                                   // the loop of src/FeatureMatching.cpp:135 does not run
-    if (!p3d || !q || !K || !R || !tr || !n || (nt > 0 && (!p2d || !t))) { set_error("null argument"); return SSVIO_ERR_INVALID; }
-    if (qstride < 32 || (nt > 0 && tstride < 32)) { set_error("descriptor stride < 32"); return SSVIO_ERR_INVALID; }
-    if (nt > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
-    if (cap < nq) { set_error("output capacity %d < %d reference points", cap, nq); return SSVIO_ERR_CAPACITY; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
-    int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
-    rc = grow(m->d_t, tcap, (size_t)std::max(nt, 1) * 32, s); if (rc) return rc; m->tRows = tcap / 32;
-    rc = grow(m->d_p3d, m->p3dCap, (size_t)nq * 3, s); if (rc) return rc;
-    rc = grow(m->d_p2d, m->p2dCap, (size_t)std::max(nt, 1) * 2, s); if (rc) return rc;
-    rc = grow(m->d_cand, m->candCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_keep, m->keepCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_out, m->outCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
-    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
-    SSVIO_HIP(hipMemcpyAsync(m->d_p3d, p3d, (size_t)nq * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    if (nt > 0) {
-        rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
-        SSVIO_HIP(hipMemcpyAsync(m->d_p2d, p2d, (size_t)nt * 2 * sizeof(double), hipMemcpyHostToDevice, s));
-    }
-    ProjectArgs a{};
-    a.p3d = m->d_p3d; a.qdesc = (const uint4*)m->d_q; a.nq = nq; a.p2d = m->d_p2d; a.tdesc = (const uint4*)m->d_t; a.nt = nt;
-    a.radian = radian;
-    for (int i = 0; i < 9; ++i) { a.K[i] = K[i]; a.R[i] = R[i]; }
-    for (int i = 0; i < 3; ++i) a.t[i] = tr[i];
-    a.threshold = m->threshold; a.nnRatio = m->nnRatio;
-    a.cand = m->d_cand; a.keep = m->d_keep; a.out = m->d_out; a.nout = m->d_nout;
-    {
-        ProfScope p(m->prof, "k_match_project", s);
-        launch_project(a, s);
-    }
-    int cnt = 0;
-    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
-    *n = cnt;
-    m->prof.resolve();
-    return SSVIO_OK;
-}
-
-int ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_rows, int max_rows, const int32_t* d_counts,
-                          const int32_t* pairs, int npairs, int mode, const void** d_matches, const int32_t** d_nmatches)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    if (!d_desc || !d_counts || !pairs || npairs <= 0 || max_rows <= 0 || set_stride_rows < max_rows) { set_error("bad batch arguments"); return SSVIO_ERR_INVALID; }
-    if (mode < 0 || mode > 2) { set_error("mode must be 0..2"); return SSVIO_ERR_INVALID; }
-    if (max_rows > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    int rc = SSVIO_OK;
-    rc = upload_pairs(m, pairs, npairs); if (rc) return rc;
-    rc = match_run(m, (const uint8_t*)d_desc, set_stride_rows, d_counts, (const uint8_t*)d_desc, set_stride_rows, d_counts,
-                   m->d_pairs, npairs, max_rows, max_rows, mode);
-    if (rc) return rc;
-    if (d_matches) *d_matches = m->d_out;
-    if (d_nmatches) *d_nmatches = m->d_nout;
-    return SSVIO_OK;
-}
-
-int ssvio_matcher_sync(ssvio_matcher* m)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    SSVIO_HIP(hipSetDevice(m->device));
-    SSVIO_HIP(hipStreamSynchronize(m->stream));
-    m->prof.resolve();
-    return SSVIO_OK;
-}
-
-int ssvio_match_batch_fetch(ssvio_matcher* m, int npairs, int max_rows, ssvio_dmatch* out, int32_t* n)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    if (npairs != m->lastPairs || max_rows != m->lastMaxRows || !n) { set_error("fetch does not match the last batch call"); return SSVIO_ERR_INVALID; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    SSVIO_HIP(hipMemcpyAsync(n, m->d_nout, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    if (out) SSVIO_HIP(hipMemcpyAsync(out, m->d_out, (size_t)npairs * max_rows * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost, m->stream));
-    SSVIO_HIP(hipStreamSynchronize(m->stream));
-    return SSVIO_OK;
-}
-
-}  // extern "C"
-
-// =====================================================================================
-// MatchByDBoW (src/FeatureMatching.cpp:58-125, :192-208)
-struct ssvio_vocab {
-    int device = 0, k = 0, L = 0, nnodes = 0, scoring = 0, weighting = 0;
-    uint4* d_cdesc = nullptr; int* d_childBegin = nullptr; int* d_child = nullptr; int* d_word = nullptr; double* d_weight = nullptr;
-};
-
-static VocabDev vocab_dev(const ssvio_vocab* v)
-{
-    VocabDev d{};
-    d.cdesc = v->d_cdesc; d.childBegin = v->d_childBegin; d.child = v->d_child; d.word = v->d_word; d.weight = v->d_weight;
-    d.L = v->L; d.nnodes = v->nnodes;
-    return d;
-}
-
-static int bow_check(ssvio_matcher* m, const ssvio_vocab* v, int levelsup)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    if (!v) { set_error("null vocabulary (MatchByDBoW needs one: ssvio_vocab_create)"); return SSVIO_ERR_INVALID; }
-    if (v->device != m->device) { set_error("vocabulary lives on device %d, matcher on %d", v->device, m->device); return SSVIO_ERR_INVALID; }
-    if (levelsup < 0) { set_error("levelsup < 0"); return SSVIO_ERR_INVALID; }
-    return SSVIO_OK;
-}
-
-static int bow_grow(ssvio_matcher* m, size_t rows)
-{
-    hipStream_t s = m->stream;
-    int rc = grow(m->d_bowWord, m->bowWordCap, rows, s); if (rc) return rc;
-    rc = grow(m->d_bowNode, m->bowNodeCap, rows, s); if (rc) return rc;
-    rc = grow(m->d_bowWeight, m->bowWeightCap, rows, s); if (rc) return rc;
-    rc = grow(m->d_sortIdx, m->sortIdxCap, rows, s); if (rc) return rc;
-    rc = grow(m->d_sortNode, m->sortNodeCap, rows, s); if (rc) return rc;
-    return grow(m->d_gnode, m->gnodeCap, rows, s);
-}
-
-// order the rows of `nsets` transformed sets by (node id, index); same row indexing as bow_run
-static void bow_sort(ssvio_matcher* m, int setStrideRows, const int* d_counts, int nsets, int maxRows, size_t rowBase)
-{
-    BowSortArgs a{};
-    a.gnode = m->d_gnode + rowBase; a.setStrideRows = setStrideRows; a.counts = d_counts; a.maxRows = maxRows;
-    a.sortedIdx = m->d_sortIdx + rowBase; a.sortedNode = m->d_sortNode + rowBase;
-    ProfScope p(m->prof, "k_bow_sort", m->stream);
-    launch_bow_sort(a, nsets, m->stream);
-}
-
-// transform the rows of `nsets` descriptor sets; per-feature results land at rowBase + set * setStrideRows + i
-static void bow_run(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* d_desc, int setStrideRows, const int* d_counts, int nsets,
-                    int maxRows, int levelsup, size_t rowBase)
-{
-    BowArgs a{};
-    a.v = vocab_dev(v); a.nidLevel = v->L - levelsup;
-    a.desc = (const uint4*)d_desc; a.setStrideRows = setStrideRows; a.counts = d_counts; a.nsets = nsets; a.maxRows = maxRows;
-    a.word = m->d_bowWord + rowBase; a.node = m->d_bowNode + rowBase; a.weight = m->d_bowWeight + rowBase; a.gnode = m->d_gnode + rowBase;
-    ProfScope p(m->prof, "k_bow_transform", m->stream);
-    launch_bow_transform(a, maxRows, m->stream);
-}
-
-extern "C" {
-
-int ssvio_vocab_create(int device, int k, int L, int nnodes, const int32_t* parent, const uint8_t* desc, const double* weight,
-                       const int32_t* word, int scoring, int weighting, ssvio_vocab** out)
-{
-    if (!out) { set_error("null argument"); return SSVIO_ERR_INVALID; }
-    *out = nullptr;
-    if (!parent || !desc || !weight || !word || nnodes < 1 || k < 1 || L < 0) { set_error("bad vocabulary arguments"); return SSVIO_ERR_INVALID; }
-    if (nnodes > (1 << 30)) { set_error("too many nodes"); return SSVIO_ERR_INVALID; }
-    std::vector<int> begin((size_t)nnodes + 1, 0), child((size_t)std::max(nnodes - 1, 1)), fill((size_t)nnodes, 0);
-    for (int n = 1; n < nnodes; ++n) {
-        if (parent[n] < 0 || parent[n] >= n) { set_error("node %d: parent %d is not an earlier node", n, parent[n]); return SSVIO_ERR_INVALID; }
-        begin[(size_t)parent[n] + 1]++;
-    }
-    for (int n = 0; n < nnodes; ++n) {
-        if (begin[(size_t)n + 1] >= (1 << 20)) { set_error("node %d has 2^20 or more children", n); return SSVIO_ERR_INVALID; }
-        begin[(size_t)n + 1] += begin[n];
-    }
-    std::vector<uint8_t> cdesc((size_t)std::max(nnodes - 1, 1) * 32);
-    for (int n = 1; n < nnodes; ++n) {                      // ascending id inside every child list
-        const int c = begin[parent[n]] + fill[parent[n]]++;
-        child[c] = n;
-        memcpy(&cdesc[(size_t)c * 32], desc + (size_t)n * 32, 32);
-    }
-    const int rc = pick_device(device);
-    if (rc) return rc;
-    SSVIO_HIP(hipSetDevice(device));
-    ssvio_vocab* v = new ssvio_vocab();
-    v->device = device; v->k = k; v->L = L; v->nnodes = nnodes; v->scoring = scoring; v->weighting = weighting;
-    bool ok = hipMalloc(&v->d_cdesc, cdesc.size()) == hipSuccess && hipMalloc(&v->d_childBegin, begin.size() * sizeof(int)) == hipSuccess &&
-              hipMalloc(&v->d_child, child.size() * sizeof(int)) == hipSuccess && hipMalloc(&v->d_word, (size_t)nnodes * sizeof(int)) == hipSuccess &&
-              hipMalloc(&v->d_weight, (size_t)nnodes * sizeof(double)) == hipSuccess;
-    ok = ok && hipMemcpy(v->d_cdesc, cdesc.data(), cdesc.size(), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(v->d_childBegin, begin.data(), begin.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(v->d_child, child.data(), child.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(v->d_word, word, (size_t)nnodes * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(v->d_weight, weight, (size_t)nnodes * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) { set_error("cannot place the vocabulary on the device"); ssvio_vocab_destroy(v); return SSVIO_ERR_HIP; }
-    *out = v;
-    return SSVIO_OK;
-}
-
-void ssvio_vocab_destroy(ssvio_vocab* v)
-{
-    if (!v) return;
-    (void)hipSetDevice(v->device);
-    (void)hipDeviceSynchronize();
-    dfree(v->d_cdesc); dfree(v->d_childBegin); dfree(v->d_child); dfree(v->d_word); dfree(v->d_weight);
-    delete v;
-}
-
-int ssvio_vocab_info(const ssvio_vocab* v, int* k, int* L, int* nnodes, int* scoring, int* weighting)
-{
-    if (!v) { set_error("null vocabulary"); return SSVIO_ERR_INVALID; }
-    if (k) *k = v->k; if (L) *L = v->L; if (nnodes) *nnodes = v->nnodes; if (scoring) *scoring = v->scoring; if (weighting) *weighting = v->weighting;
-    return SSVIO_OK;
-}
-
-int ssvio_bow_transform(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* desc, int n, int stride, int levelsup,
-                        int32_t* word, int32_t* node, double* weight)
-{
-    int rc = bow_check(m, v, levelsup); if (rc) return rc;
-    if (n < 0) { set_error("negative row count"); return SSVIO_ERR_INVALID; }
-    if (n == 0) return SSVIO_OK;
-    if (!desc || stride < 32) { set_error("bad descriptor matrix"); return SSVIO_ERR_INVALID; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    size_t qcap = m->qRows * 32;
-    rc = grow(m->d_q, qcap, (size_t)n * 32, s); if (rc) return rc; m->qRows = qcap / 32;
-    rc = bow_grow(m, (size_t)n); if (rc) return rc;
-    rc = upload_rows(m->d_q, desc, n, stride, m->stageQ, s); if (rc) return rc;
-    const int counts[2] = {n, 0};
-    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    bow_run(m, v, m->d_q, 0, m->d_counts2, 1, n, levelsup, 0);
-    if (word) SSVIO_HIP(hipMemcpyAsync(word, m->d_bowWord, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    if (node) SSVIO_HIP(hipMemcpyAsync(node, m->d_bowNode, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    if (weight) SSVIO_HIP(hipMemcpyAsync(weight, m->d_bowWeight, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    m->prof.resolve();
-    m->lastBowQ = n; m->lastBowT = 0;
-    return SSVIO_OK;
-}
-
-int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, int nq, int qstride,
-                     const uint8_t* t, int nt, int tstride, int levelsup, ssvio_dmatch* out, int cap, int* n)
-{
-    int rc = bow_check(m, v, levelsup); if (rc) return rc;
-    if (n) *n = 0;
-    if (nq < 0 || nt < 0) { set_error("negative row count"); return SSVIO_ERR_INVALID; }
-    if (!(nq > 0 && nt > 0)) return SSVIO_OK;                          // src/FeatureMatching.cpp:61-63
-    if (!q || !t || !out || !n) { set_error("null argument"); return SSVIO_ERR_INVALID; }
-    if (qstride < 32 || tstride < 32) { set_error("descriptor stride < 32"); return SSVIO_ERR_INVALID; }
-    if (nt > (1 << 23) - 2 || nq > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
-    if (cap < nq) { set_error("output capacity %d < %d query rows", cap, nq); return SSVIO_ERR_CAPACITY; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
-    rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
-    rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
-    rc = bow_grow(m, (size_t)nq + nt); if (rc) return rc;
-    rc = grow(m->d_cand, m->candCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_keepNode, m->keepNodeCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_out, m->outCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
-    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
-    rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
-    const int counts[2] = {nq, nt};
-    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    bow_run(m, v, m->d_q, 0, m->d_counts2, 1, nq, levelsup, 0);               // ComputeBoWVector(desp1), :68
-    bow_run(m, v, m->d_t, 0, m->d_counts2 + 1, 1, nt, levelsup, (size_t)nq);  // ComputeBoWVector(desp2), :69
-    if (std::max(nq, nt) <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED")) {
-        bow_sort(m, 0, m->d_counts2, 1, nq, 0);
-        bow_sort(m, 0, m->d_counts2 + 1, 1, nt, (size_t)nq);
-        SortedMatchArgs g{};
-        g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t;
-        g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx + nq; g.tSortedNode = m->d_sortNode + nq;
-        g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
-        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq; g.maxT = nt;
-        g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
-        ProfScope p(m->prof, "k_match_sorted", s);
-        launch_match_sorted(g, nq, nt, 1, s);
-    } else {                                                           // sets beyond the LDS sort: wave per query over all train rows
-        GroupedArgs g{};
-        g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + nq;
-        g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
-        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq; g.maxT = nt;
-        g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
-        ProfScope p(m->prof, "k_match_grouped", s);
-        launch_match_grouped(g, nq, 1, s);
-    }
-    int cnt = 0;
-    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
-    *n = cnt;
-    m->prof.resolve();
-    m->lastBowQ = nq; m->lastBowT = nt;
-    return SSVIO_OK;
-}
-
-int ssvio_bow_last_transform(ssvio_matcher* m, int side, int32_t* word, int32_t* node, double* weight, int cap, int* n)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    if (side != 0 && side != 1) { set_error("side must be 0 (desp1) or 1 (desp2)"); return SSVIO_ERR_INVALID; }
-    const int rows = side ? m->lastBowT : m->lastBowQ;
-    const size_t base = side ? (size_t)m->lastBowQ : 0;
-    if (n) *n = rows;
-    if (rows == 0) return SSVIO_OK;
-    if (cap < rows) { set_error("capacity %d < %d rows", cap, rows); return SSVIO_ERR_CAPACITY; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    if (word) SSVIO_HIP(hipMemcpyAsync(word, m->d_bowWord + base, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
-    if (node) SSVIO_HIP(hipMemcpyAsync(node, m->d_bowNode + base, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
-    if (weight) SSVIO_HIP(hipMemcpyAsync(weight, m->d_bowWeight + base, (size_t)rows * 8, hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    return SSVIO_OK;
-}
-
-int ssvio_match_dbow_batch_dev(ssvio_matcher* m, const ssvio_vocab* v, const void* d_desc, int set_stride_rows, int max_rows,
-                               const int32_t* d_counts, int nsets, const int32_t* pairs, int npairs, int levelsup,
-                               const void** d_matches, const int32_t** d_nmatches)
-{
-    int rc = bow_check(m, v, levelsup); if (rc) return rc;
-    if (!d_desc || !d_counts || !pairs || npairs <= 0 || nsets <= 0 || max_rows <= 0 || set_stride_rows < max_rows) { set_error("bad batch arguments"); return SSVIO_ERR_INVALID; }
-    if (max_rows > (1 << 23) - 2) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
-    for (int i = 0; i < 2 * npairs; ++i) if (pairs[i] < 0 || pairs[i] >= nsets) { set_error("pair %d names set %d of %d", i / 2, pairs[i], nsets); return SSVIO_ERR_INVALID; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    rc = upload_pairs(m, pairs, npairs); if (rc) return rc;
-    rc = bow_grow(m, (size_t)nsets * set_stride_rows); if (rc) return rc;
-    rc = grow(m->d_cand, m->candCap, (size_t)npairs * max_rows, s); if (rc) return rc;
-    rc = grow(m->d_keepNode, m->keepNodeCap, (size_t)npairs * max_rows, s); if (rc) return rc;
-    rc = grow(m->d_out, m->outCap, (size_t)npairs * max_rows, s); if (rc) return rc;
-    rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
-    bow_run(m, v, (const uint8_t*)d_desc, set_stride_rows, d_counts, nsets, max_rows, levelsup, 0);   // once per set, not per pair
-    if (max_rows <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED")) {
-        bow_sort(m, set_stride_rows, d_counts, nsets, max_rows, 0);
-        SortedMatchArgs g{};
-        g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc;
-        g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx; g.tSortedNode = m->d_sortNode;
-        g.qSetStrideRows = set_stride_rows; g.tSetStrideRows = set_stride_rows; g.qcounts = d_counts; g.tcounts = d_counts; g.pairs = m->d_pairs;
-        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows; g.maxT = max_rows;
-        g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
-        ProfScope p(m->prof, "k_match_sorted", s);
-        launch_match_sorted(g, max_rows, max_rows, npairs, s);
-    } else {
-        GroupedArgs g{};
-        g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode;
-        g.qSetStrideRows = set_stride_rows; g.tSetStrideRows = set_stride_rows; g.qcounts = d_counts; g.tcounts = d_counts; g.pairs = m->d_pairs;
-        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows; g.maxT = max_rows;
-        g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
-        ProfScope p(m->prof, "k_match_grouped", s);
-        launch_match_grouped(g, max_rows, npairs, s);
-    }
-    m->lastPairs = npairs; m->lastMaxRows = max_rows;
-    m->lastBowQ = 0; m->lastBowT = 0;
-    if (d_matches) *d_matches = m->d_out;
-    if (d_nmatches) *d_nmatches = m->d_nout;
-    return SSVIO_OK;
-}
-
-}  // extern "C"
-
-// =====================================================================================
-// behind the matcher
-static int cam_dev(const ssvio_camera* cam, int w, int h, int stride_px, FrameCam& c)
-{
-    if (!cam) { set_error("null camera"); return SSVIO_ERR_INVALID; }
-    if (w <= 0 || h <= 0 || stride_px < w) { set_error("bad depth image geometry %dx%d stride %d", w, h, stride_px); return SSVIO_ERR_INVALID; }
-    c.cx = cam->cx; c.cy = cam->cy;
-    c.invFx = 1 / cam->fx; c.invFy = 1 / cam->fy;                    // include/Init.h:19-20
-    c.depthScale = cam->depth_scale; c.w = w; c.h = h; c.stridePx = stride_px;
-    return SSVIO_OK;
-}
-
-static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-
-// carve the assembled-list block of the handle into its seven arrays + counts
-static int assemble_outputs(ssvio_matcher* m, int npairs, int maxRows, AssembleArgs& a)
-{
-    const size_t rows = (size_t)npairs * maxRows;
-    const size_t s3 = align256(rows * 12), s2 = align256(rows * 8), sm = align256(rows * 16), sc = align256((size_t)npairs * 8);
-    int rc = grow(m->d_frameOut, m->frameOutCap, 4 * s3 + s2 + 2 * sm + sc, m->stream); if (rc) return rc;
-    uint8_t* p = m->d_frameOut;
-    a.last3d = (float*)p; p += s3; a.cur3d = (float*)p; p += s3; a.edgeLast3d = (float*)p; p += s3; a.edgeCur3d = (float*)p; p += s3;
-    a.cur2d = (float*)p; p += s2; a.preGood = (ssvio_dmatch*)p; p += sm; a.finalGood = (ssvio_dmatch*)p; p += sm; a.counts = (int*)p;
-    return SSVIO_OK;
-}
-
-extern "C" {
-
-int ssvio_get_3d_points(ssvio_matcher* m, const ssvio_keypoint* kps, int n, const uint16_t* depth, int w, int h, int stride_px,
-                        const ssvio_camera* cam, float* out)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    FrameCam c; int rc = cam_dev(cam, w, h, stride_px, c); if (rc) return rc;
-    if (n < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
-    if (n == 0) return SSVIO_OK;
-    if (!kps || !depth || !out) { set_error("null argument"); return SSVIO_ERR_INVALID; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    const size_t kb = align256((size_t)n * sizeof(ssvio_keypoint)), db = align256((size_t)h * stride_px * 2);
-    rc = grow(m->d_frameIn, m->frameInCap, kb + db, s); if (rc) return rc;
-    rc = grow(m->d_frameOut, m->frameOutCap, (size_t)n * 12, s); if (rc) return rc;
-    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, kps, (size_t)n * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn + kb, depth, (size_t)h * stride_px * 2, hipMemcpyHostToDevice, s));
-    {
-        ProfScope p(m->prof, "k_get_3d_points", s);
-        launch_get_3d_points((const ssvio_keypoint*)m->d_frameIn, n, (const uint16_t*)(m->d_frameIn + kb), c, (float*)m->d_frameOut, s);
-    }
-    SSVIO_HIP(hipMemcpyAsync(out, m->d_frameOut, (size_t)n * 12, hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    m->prof.resolve();
-    return SSVIO_OK;
-}
-
-int ssvio_assemble_correspondences(ssvio_matcher* m, const ssvio_dmatch* matches, int nm,
-                                   const ssvio_keypoint* last_kps, int nlast, const uint16_t* last_depth,
-                                   const ssvio_keypoint* cur_kps, int ncur, const uint16_t* cur_depth,
-                                   int w, int h, int stride_px, const ssvio_camera* cam,
-                                   float* last3d, float* cur2d, float* cur3d, ssvio_dmatch* pre_good, int* n_pre,
-                                   float* edge_last3d, float* edge_cur3d, ssvio_dmatch* final_good, int* n_final)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    FrameCam c; int rc = cam_dev(cam, w, h, stride_px, c); if (rc) return rc;
-    if (n_pre) *n_pre = 0;
-    if (n_final) *n_final = 0;
-    if (nm < 0 || nlast < 0 || ncur < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
-    if (nm == 0) return SSVIO_OK;                                   // the loop of src/Odometry.cpp:44 does not run
-    if (!matches || !last_kps || !cur_kps || !last_depth || !cur_depth || !last3d || !cur2d || !cur3d || !pre_good || !n_pre ||
-        !edge_last3d || !edge_cur3d || !final_good || !n_final) { set_error("null argument"); return SSVIO_ERR_INVALID; }
-    for (int i = 0; i < nm; ++i)
-        if (matches[i].trainIdx < 0 || matches[i].trainIdx >= nlast || matches[i].queryIdx < 0 || matches[i].queryIdx >= ncur) {
-            set_error("match %d (query %d, train %d) is outside the keypoint lists (%d, %d)", i, matches[i].queryIdx, matches[i].trainIdx, ncur, nlast);
-            return SSVIO_ERR_INVALID;
-        }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    const int kpStride = std::max(std::max(nlast, ncur), 1);
-    const size_t depthPx = (size_t)h * stride_px;
-    const size_t mb = align256((size_t)nm * 16), kb = align256((size_t)2 * kpStride * sizeof(ssvio_keypoint)), db = align256(2 * depthPx * 2);
-    rc = grow(m->d_frameIn, m->frameInCap, mb + kb + db + 256, s); if (rc) return rc;
-    uint8_t* d_m = m->d_frameIn; uint8_t* d_k = d_m + mb; uint8_t* d_d = d_k + kb; int* d_c = (int*)(d_d + db);   // {nm, ncur, nlast}
-    SSVIO_HIP(hipMemcpyAsync(d_m, matches, (size_t)nm * 16, hipMemcpyHostToDevice, s));
-    if (ncur) SSVIO_HIP(hipMemcpyAsync(d_k, cur_kps, (size_t)ncur * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));       // set 0 = current
-    if (nlast) SSVIO_HIP(hipMemcpyAsync(d_k + (size_t)kpStride * sizeof(ssvio_keypoint), last_kps, (size_t)nlast * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipMemcpyAsync(d_d, cur_depth, depthPx * 2, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipMemcpyAsync(d_d + depthPx * 2, last_depth, depthPx * 2, hipMemcpyHostToDevice, s));
-    const int cnts[3] = {nm, ncur, nlast};
-    SSVIO_HIP(hipMemcpyAsync(d_c, cnts, sizeof cnts, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipStreamSynchronize(s));                             // `cnts` is a stack array
-    AssembleArgs a{};
-    a.matches = (const ssvio_dmatch*)d_m; a.nmatches = d_c; a.maxRows = nm; a.pairs = nullptr;
-    a.kps = (const ssvio_keypoint*)d_k; a.kpStride = kpStride; a.kpCounts = d_c + 1;
-    a.depth = (const uint16_t*)d_d; a.depthFrameStride = depthPx; a.cam = c;
-    rc = assemble_outputs(m, 1, nm, a); if (rc) return rc;
-    {
-        ProfScope p(m->prof, "k_assemble", s);
-        launch_assemble(a, 1, s);
-    }
-    int got[2] = {0, 0};
-    SSVIO_HIP(hipMemcpyAsync(got, a.counts, sizeof got, hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    const size_t np = (size_t)got[0], nf = (size_t)got[1];
-    if (np) {
-        SSVIO_HIP(hipMemcpyAsync(last3d, a.last3d, np * 12, hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(cur2d, a.cur2d, np * 8, hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(cur3d, a.cur3d, np * 12, hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(pre_good, a.preGood, np * 16, hipMemcpyDeviceToHost, s));
-    }
-    if (nf) {
-        SSVIO_HIP(hipMemcpyAsync(edge_last3d, a.edgeLast3d, nf * 12, hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(edge_cur3d, a.edgeCur3d, nf * 12, hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(final_good, a.finalGood, nf * 16, hipMemcpyDeviceToHost, s));
-    }
-    SSVIO_HIP(hipStreamSynchronize(s));
-    *n_pre = got[0]; *n_final = got[1];
-    m->prof.resolve();
-    return SSVIO_OK;
-}
-
-int ssvio_assemble_batch_dev(ssvio_matcher* m, const void* d_matches, const int32_t* d_nmatches, int max_rows,
-                             const int32_t* pairs, int npairs, const void* d_kps, int kp_stride, const int32_t* d_kpcounts,
-                             const void* d_depth, size_t depth_frame_stride, int w, int h, int stride_px,
-                             const ssvio_camera* cam, ssvio_correspondences_dev* out)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    FrameCam c; int rc = cam_dev(cam, w, h, stride_px, c); if (rc) return rc;
-    if (!d_matches || !d_nmatches || !pairs || !d_kps || !d_kpcounts || !d_depth || !out || npairs <= 0 || max_rows <= 0 || kp_stride <= 0 ||
-        depth_frame_stride < (size_t)h * stride_px) { set_error("bad batch arguments"); return SSVIO_ERR_INVALID; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    rc = upload_pairs(m, pairs, npairs); if (rc) return rc;
-    AssembleArgs a{};
-    a.matches = (const ssvio_dmatch*)d_matches; a.nmatches = d_nmatches; a.maxRows = max_rows; a.pairs = m->d_pairs;
-    a.kps = (const ssvio_keypoint*)d_kps; a.kpStride = kp_stride; a.kpCounts = d_kpcounts;
-    a.depth = (const uint16_t*)d_depth; a.depthFrameStride = depth_frame_stride; a.cam = c;
-    rc = assemble_outputs(m, npairs, max_rows, a); if (rc) return rc;
-    {
-        ProfScope p(m->prof, "k_assemble", m->stream);
-        launch_assemble(a, npairs, m->stream);
-    }
-    out->last3d = a.last3d; out->cur2d = a.cur2d; out->cur3d = a.cur3d; out->pre_good = a.preGood;
-    out->edge_last3d = a.edgeLast3d; out->edge_cur3d = a.edgeCur3d; out->final_good = a.finalGood; out->counts = a.counts;
-    return SSVIO_OK;
-}
-
-// index map over a DMatch list on the device: table[key] = first position (0xFFFFFFFF = none)
-static int first_index_table(ssvio_matcher* m, const ssvio_dmatch* d_v, int n, int useTrain, int tableSize)
-{
-    hipStream_t s = m->stream;
-    int rc = grow(m->d_table, m->tableCap, (size_t)std::max(tableSize, 1), s); if (rc) return rc;
-    SSVIO_HIP(hipMemsetAsync(m->d_table, 0xFF, (size_t)std::max(tableSize, 1) * 4, s));
-    ProfScope p(m->prof, "k_first_index", s);
-    launch_first_index(d_v, n, useTrain, m->d_table, tableSize, s);
-    return SSVIO_OK;
-}
-
-int ssvio_track_map_points(ssvio_matcher* m, const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, int ncur,
-                           ssvio_dmatch* out, int cap, int* n)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    if (n) *n = 0;
-    if (nlast < 0 || ncur < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
-    if (nlast == 0 || ncur == 0) return SSVIO_OK;                    // no pair can meet: last_match_vec becomes empty (src/Map.cpp:121-122)
-    if (!last || !cur || !out || !n) { set_error("null argument"); return SSVIO_ERR_INVALID; }
-    if (cap < nlast) { set_error("output capacity %d < %d", cap, nlast); return SSVIO_ERR_CAPACITY; }
-    int maxKey = -1;                                                 // the map covers the keys the join can ask for
-    for (int i = 0; i < nlast; ++i) maxKey = std::max(maxKey, last[i].queryIdx);
-    if (maxKey < 0) return SSVIO_OK;
-    if (maxKey >= (1 << 28)) { set_error("queryIdx %d too large for an index map", maxKey); return SSVIO_ERR_INVALID; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    const size_t lb = align256((size_t)nlast * 16), cb = align256((size_t)ncur * 16);
-    int rc = grow(m->d_frameIn, m->frameInCap, lb + cb, s); if (rc) return rc;
-    rc = grow(m->d_out, m->outCap, (size_t)nlast, s); if (rc) return rc;
-    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
-    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, last, (size_t)nlast * 16, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn + lb, cur, (size_t)ncur * 16, hipMemcpyHostToDevice, s));
-    rc = first_index_table(m, (const ssvio_dmatch*)(m->d_frameIn + lb), ncur, 1, maxKey + 1); if (rc) return rc;
-    {
-        ProfScope p(m->prof, "k_track", s);
-        launch_track((const ssvio_dmatch*)m->d_frameIn, nlast, (const ssvio_dmatch*)(m->d_frameIn + lb), m->d_table, maxKey + 1, m->d_out, m->d_nout, s);
-    }
-    int cnt = 0;
-    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
-    *n = cnt;
-    m->prof.resolve();
-    return SSVIO_OK;
-}
-
-int ssvio_in_match_vec(ssvio_matcher* m, const ssvio_dmatch* vec, int n, int nkp, int32_t* out)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    if (n < 0 || nkp < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
-    if (nkp == 0) return SSVIO_OK;
-    if (!out || (n > 0 && !vec)) { set_error("null argument"); return SSVIO_ERR_INVALID; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    int rc = grow(m->d_frameIn, m->frameInCap, (size_t)std::max(n, 1) * 16, s); if (rc) return rc;
-    if (n) SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, vec, (size_t)n * 16, hipMemcpyHostToDevice, s));
-    rc = first_index_table(m, (const ssvio_dmatch*)m->d_frameIn, n, 0, nkp); if (rc) return rc;
-    SSVIO_HIP(hipMemcpyAsync(out, m->d_table, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));    // 0xFFFFFFFF reads as -1
-    SSVIO_HIP(hipStreamSynchronize(s));
-    m->prof.resolve();
-    return SSVIO_OK;
-}
-
-}  // extern "C"
-
-extern "C" int ssvio_rgb_cloud(ssvio_matcher* m, const uint16_t* depth, int depth_stride_px, const uint8_t* bgr, int bgr_stride,
-                               int w, int h, const ssvio_camera* cam, double depth_scale, void* out)
-{
-    if (mt_check(m)) return SSVIO_ERR_INVALID;
-    FrameCam c; int rc = cam_dev(cam, w, h, depth_stride_px, c); if (rc) return rc;
-    if (!depth || !bgr || !out || bgr_stride < 3 * w) { set_error("bad cloud arguments"); return SSVIO_ERR_INVALID; }
-    if ((size_t)w * h > ((size_t)1 << 28)) { set_error("image too large"); return SSVIO_ERR_INVALID; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    const size_t db = align256((size_t)h * depth_stride_px * 2), cb = align256((size_t)h * bgr_stride), ob = (size_t)w * h * 32;
-    rc = grow(m->d_frameIn, m->frameInCap, db + cb, s); if (rc) return rc;
-    rc = grow(m->d_frameOut, m->frameOutCap, ob, s); if (rc) return rc;
-    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, depth, (size_t)h * depth_stride_px * 2, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn + db, bgr, (size_t)h * bgr_stride, hipMemcpyHostToDevice, s));
-    {
-        ProfScope p(m->prof, "k_rgb_cloud", s);
-        launch_rgb_cloud((const uint16_t*)m->d_frameIn, depth_stride_px, m->d_frameIn + db, bgr_stride, w, h, c.cx, c.cy, c.invFx, c.invFy,
-                         depth_scale, m->d_frameOut, s);
-    }
-    SSVIO_HIP(hipMemcpyAsync(out, m->d_frameOut, ob, hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    m->prof.resolve();
-    return SSVIO_OK;
-}

@@ -1,0 +1,264 @@
+// capi_bow.hip -- the C ABI of include/ssvio_gpu.h, part 3: the vocabulary handle and MatchByDBoW.
+#include "capi_internal.h"
+
+// =====================================================================================
+// MatchByDBoW (src/FeatureMatching.cpp:58-125, :192-208)
+struct ssvio_vocab {
+    int device = 0, k = 0, L = 0, nnodes = 0, scoring = 0, weighting = 0;
+    uint4* d_cdesc = nullptr; int* d_childBegin = nullptr; int* d_child = nullptr; int* d_word = nullptr; double* d_weight = nullptr;
+};
+
+static VocabDev vocab_dev(const ssvio_vocab* v)
+{
+    VocabDev d{};
+    d.cdesc = v->d_cdesc; d.childBegin = v->d_childBegin; d.child = v->d_child; d.word = v->d_word; d.weight = v->d_weight;
+    d.L = v->L; d.nnodes = v->nnodes;
+    return d;
+}
+
+static int bow_check(ssvio_matcher* m, const ssvio_vocab* v, int levelsup)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (!v) { set_error("null vocabulary (MatchByDBoW needs one: ssvio_vocab_create)"); return SSVIO_ERR_INVALID; }
+    if (v->device != m->device) { set_error("vocabulary lives on device %d, matcher on %d", v->device, m->device); return SSVIO_ERR_INVALID; }
+    if (levelsup < 0) { set_error("levelsup < 0"); return SSVIO_ERR_INVALID; }
+    return SSVIO_OK;
+}
+
+static int bow_grow(ssvio_matcher* m, size_t rows)
+{
+    hipStream_t s = m->stream;
+    int rc = grow(m->d_bowWord, m->bowWordCap, rows, s); if (rc) return rc;
+    rc = grow(m->d_bowNode, m->bowNodeCap, rows, s); if (rc) return rc;
+    rc = grow(m->d_bowWeight, m->bowWeightCap, rows, s); if (rc) return rc;
+    rc = grow(m->d_sortIdx, m->sortIdxCap, rows, s); if (rc) return rc;
+    rc = grow(m->d_sortNode, m->sortNodeCap, rows, s); if (rc) return rc;
+    return grow(m->d_gnode, m->gnodeCap, rows, s);
+}
+
+// order the rows of `nsets` transformed sets by (node id, index); same row indexing as bow_run
+static void bow_sort(ssvio_matcher* m, int setStrideRows, const int* d_counts, int nsets, int maxRows, size_t rowBase)
+{
+    BowSortArgs a{};
+    a.gnode = m->d_gnode + rowBase; a.setStrideRows = setStrideRows; a.counts = d_counts; a.maxRows = maxRows;
+    a.sortedIdx = m->d_sortIdx + rowBase; a.sortedNode = m->d_sortNode + rowBase;
+    ProfScope p(m->prof, "k_bow_sort", m->stream);
+    launch_bow_sort(a, nsets, m->stream);
+}
+
+// transform the rows of `nsets` descriptor sets; per-feature results land at rowBase + set * setStrideRows + i
+static void bow_run(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* d_desc, int setStrideRows, const int* d_counts, int nsets,
+                    int maxRows, int levelsup, size_t rowBase)
+{
+    BowArgs a{};
+    a.v = vocab_dev(v); a.nidLevel = v->L - levelsup;
+    a.desc = (const uint4*)d_desc; a.setStrideRows = setStrideRows; a.counts = d_counts; a.nsets = nsets; a.maxRows = maxRows;
+    a.word = m->d_bowWord + rowBase; a.node = m->d_bowNode + rowBase; a.weight = m->d_bowWeight + rowBase; a.gnode = m->d_gnode + rowBase;
+    ProfScope p(m->prof, "k_bow_transform", m->stream);
+    launch_bow_transform(a, maxRows, m->stream);
+}
+
+extern "C" {
+
+int ssvio_vocab_create(int device, int k, int L, int nnodes, const int32_t* parent, const uint8_t* desc, const double* weight,
+                       const int32_t* word, int scoring, int weighting, ssvio_vocab** out)
+{
+    if (!out) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    *out = nullptr;
+    if (!parent || !desc || !weight || !word || nnodes < 1 || k < 1 || L < 0) { set_error("bad vocabulary arguments"); return SSVIO_ERR_INVALID; }
+    if (nnodes > (1 << 30)) { set_error("too many nodes"); return SSVIO_ERR_INVALID; }
+    std::vector<int> begin((size_t)nnodes + 1, 0), child((size_t)std::max(nnodes - 1, 1)), fill((size_t)nnodes, 0);
+    for (int n = 1; n < nnodes; ++n) {
+        if (parent[n] < 0 || parent[n] >= n) { set_error("node %d: parent %d is not an earlier node", n, parent[n]); return SSVIO_ERR_INVALID; }
+        begin[(size_t)parent[n] + 1]++;
+    }
+    for (int n = 0; n < nnodes; ++n) {
+        if (begin[(size_t)n + 1] >= (1 << 20)) { set_error("node %d has 2^20 or more children", n); return SSVIO_ERR_INVALID; }
+        begin[(size_t)n + 1] += begin[n];
+    }
+    std::vector<uint8_t> cdesc((size_t)std::max(nnodes - 1, 1) * 32);
+    for (int n = 1; n < nnodes; ++n) {                      // ascending id inside every child list
+        const int c = begin[parent[n]] + fill[parent[n]]++;
+        child[c] = n;
+        memcpy(&cdesc[(size_t)c * 32], desc + (size_t)n * 32, 32);
+    }
+    const int rc = pick_device(device);
+    if (rc) return rc;
+    SSVIO_HIP(hipSetDevice(device));
+    ssvio_vocab* v = new ssvio_vocab();
+    v->device = device; v->k = k; v->L = L; v->nnodes = nnodes; v->scoring = scoring; v->weighting = weighting;
+    bool ok = hipMalloc(&v->d_cdesc, cdesc.size()) == hipSuccess && hipMalloc(&v->d_childBegin, begin.size() * sizeof(int)) == hipSuccess &&
+              hipMalloc(&v->d_child, child.size() * sizeof(int)) == hipSuccess && hipMalloc(&v->d_word, (size_t)nnodes * sizeof(int)) == hipSuccess &&
+              hipMalloc(&v->d_weight, (size_t)nnodes * sizeof(double)) == hipSuccess;
+    ok = ok && hipMemcpy(v->d_cdesc, cdesc.data(), cdesc.size(), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_childBegin, begin.data(), begin.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_child, child.data(), child.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_word, word, (size_t)nnodes * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(v->d_weight, weight, (size_t)nnodes * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { set_error("cannot place the vocabulary on the device"); ssvio_vocab_destroy(v); return SSVIO_ERR_HIP; }
+    *out = v;
+    return SSVIO_OK;
+}
+
+void ssvio_vocab_destroy(ssvio_vocab* v)
+{
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    (void)hipDeviceSynchronize();
+    dfree(v->d_cdesc); dfree(v->d_childBegin); dfree(v->d_child); dfree(v->d_word); dfree(v->d_weight);
+    delete v;
+}
+
+int ssvio_vocab_info(const ssvio_vocab* v, int* k, int* L, int* nnodes, int* scoring, int* weighting)
+{
+    if (!v) { set_error("null vocabulary"); return SSVIO_ERR_INVALID; }
+    if (k) *k = v->k; if (L) *L = v->L; if (nnodes) *nnodes = v->nnodes; if (scoring) *scoring = v->scoring; if (weighting) *weighting = v->weighting;
+    return SSVIO_OK;
+}
+
+int ssvio_bow_transform(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* desc, int n, int stride, int levelsup,
+                        int32_t* word, int32_t* node, double* weight)
+{
+    int rc = bow_check(m, v, levelsup); if (rc) return rc;
+    if (n < 0) { set_error("negative row count"); return SSVIO_ERR_INVALID; }
+    if (n == 0) return SSVIO_OK;
+    if (!desc || stride < 32) { set_error("bad descriptor matrix"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    size_t qcap = m->qRows * 32;
+    rc = grow(m->d_q, qcap, (size_t)n * 32, s); if (rc) return rc; m->qRows = qcap / 32;
+    rc = bow_grow(m, (size_t)n); if (rc) return rc;
+    rc = upload_rows(m->d_q, desc, n, stride, m->stageQ, s); if (rc) return rc;
+    const int counts[2] = {n, 0};
+    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    bow_run(m, v, m->d_q, 0, m->d_counts2, 1, n, levelsup, 0);
+    if (word) SSVIO_HIP(hipMemcpyAsync(word, m->d_bowWord, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (node) SSVIO_HIP(hipMemcpyAsync(node, m->d_bowNode, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (weight) SSVIO_HIP(hipMemcpyAsync(weight, m->d_bowWeight, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    m->prof.resolve();
+    m->lastBowQ = n; m->lastBowT = 0;
+    return SSVIO_OK;
+}
+
+int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, int nq, int qstride,
+                     const uint8_t* t, int nt, int tstride, int levelsup, ssvio_dmatch* out, int cap, int* n)
+{
+    int rc = bow_check(m, v, levelsup); if (rc) return rc;
+    if (n) *n = 0;
+    if (nq < 0 || nt < 0) { set_error("negative row count"); return SSVIO_ERR_INVALID; }
+    if (!(nq > 0 && nt > 0)) return SSVIO_OK;                          // src/FeatureMatching.cpp:61-63
+    if (!q || !t || !out || !n) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    if (qstride < 32 || tstride < 32) { set_error("descriptor stride < 32"); return SSVIO_ERR_INVALID; }
+    if (nt > (1 << 23) - 2 || nq > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
+    if (cap < nq) { set_error("output capacity %d < %d query rows", cap, nq); return SSVIO_ERR_CAPACITY; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
+    rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
+    rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
+    rc = bow_grow(m, (size_t)nq + nt); if (rc) return rc;
+    rc = grow(m->d_cand, m->candCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_keepNode, m->keepNodeCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_out, m->outCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
+    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
+    rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
+    const int counts[2] = {nq, nt};
+    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    bow_run(m, v, m->d_q, 0, m->d_counts2, 1, nq, levelsup, 0);               // ComputeBoWVector(desp1), :68
+    bow_run(m, v, m->d_t, 0, m->d_counts2 + 1, 1, nt, levelsup, (size_t)nq);  // ComputeBoWVector(desp2), :69
+    if (std::max(nq, nt) <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED")) {
+        bow_sort(m, 0, m->d_counts2, 1, nq, 0);
+        bow_sort(m, 0, m->d_counts2 + 1, 1, nt, (size_t)nq);
+        SortedMatchArgs g{};
+        g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t;
+        g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx + nq; g.tSortedNode = m->d_sortNode + nq;
+        g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq; g.maxT = nt;
+        g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
+        ProfScope p(m->prof, "k_match_sorted", s);
+        launch_match_sorted(g, nq, nt, 1, s);
+    } else {                                                           // sets beyond the LDS sort: wave per query over all train rows
+        GroupedArgs g{};
+        g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + nq;
+        g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq; g.maxT = nt;
+        g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
+        ProfScope p(m->prof, "k_match_grouped", s);
+        launch_match_grouped(g, nq, 1, s);
+    }
+    int cnt = 0;
+    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+    *n = cnt;
+    m->prof.resolve();
+    m->lastBowQ = nq; m->lastBowT = nt;
+    return SSVIO_OK;
+}
+
+int ssvio_bow_last_transform(ssvio_matcher* m, int side, int32_t* word, int32_t* node, double* weight, int cap, int* n)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (side != 0 && side != 1) { set_error("side must be 0 (desp1) or 1 (desp2)"); return SSVIO_ERR_INVALID; }
+    const int rows = side ? m->lastBowT : m->lastBowQ;
+    const size_t base = side ? (size_t)m->lastBowQ : 0;
+    if (n) *n = rows;
+    if (rows == 0) return SSVIO_OK;
+    if (cap < rows) { set_error("capacity %d < %d rows", cap, rows); return SSVIO_ERR_CAPACITY; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    if (word) SSVIO_HIP(hipMemcpyAsync(word, m->d_bowWord + base, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+    if (node) SSVIO_HIP(hipMemcpyAsync(node, m->d_bowNode + base, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
+    if (weight) SSVIO_HIP(hipMemcpyAsync(weight, m->d_bowWeight + base, (size_t)rows * 8, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    return SSVIO_OK;
+}
+
+int ssvio_match_dbow_batch_dev(ssvio_matcher* m, const ssvio_vocab* v, const void* d_desc, int set_stride_rows, int max_rows,
+                               const int32_t* d_counts, int nsets, const int32_t* pairs, int npairs, int levelsup,
+                               const void** d_matches, const int32_t** d_nmatches)
+{
+    int rc = bow_check(m, v, levelsup); if (rc) return rc;
+    if (!d_desc || !d_counts || !pairs || npairs <= 0 || nsets <= 0 || max_rows <= 0 || set_stride_rows < max_rows) { set_error("bad batch arguments"); return SSVIO_ERR_INVALID; }
+    if (max_rows > (1 << 23) - 2) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
+    for (int i = 0; i < 2 * npairs; ++i) if (pairs[i] < 0 || pairs[i] >= nsets) { set_error("pair %d names set %d of %d", i / 2, pairs[i], nsets); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    rc = upload_pairs(m, pairs, npairs); if (rc) return rc;
+    rc = bow_grow(m, (size_t)nsets * set_stride_rows); if (rc) return rc;
+    rc = grow(m->d_cand, m->candCap, (size_t)npairs * max_rows, s); if (rc) return rc;
+    rc = grow(m->d_keepNode, m->keepNodeCap, (size_t)npairs * max_rows, s); if (rc) return rc;
+    rc = grow(m->d_out, m->outCap, (size_t)npairs * max_rows, s); if (rc) return rc;
+    rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
+    bow_run(m, v, (const uint8_t*)d_desc, set_stride_rows, d_counts, nsets, max_rows, levelsup, 0);   // once per set, not per pair
+    if (max_rows <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED")) {
+        bow_sort(m, set_stride_rows, d_counts, nsets, max_rows, 0);
+        SortedMatchArgs g{};
+        g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc;
+        g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx; g.tSortedNode = m->d_sortNode;
+        g.qSetStrideRows = set_stride_rows; g.tSetStrideRows = set_stride_rows; g.qcounts = d_counts; g.tcounts = d_counts; g.pairs = m->d_pairs;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows; g.maxT = max_rows;
+        g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
+        ProfScope p(m->prof, "k_match_sorted", s);
+        launch_match_sorted(g, max_rows, max_rows, npairs, s);
+    } else {
+        GroupedArgs g{};
+        g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode;
+        g.qSetStrideRows = set_stride_rows; g.tSetStrideRows = set_stride_rows; g.qcounts = d_counts; g.tcounts = d_counts; g.pairs = m->d_pairs;
+        g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = max_rows; g.maxT = max_rows;
+        g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
+        ProfScope p(m->prof, "k_match_grouped", s);
+        launch_match_grouped(g, max_rows, npairs, s);
+    }
+    m->lastPairs = npairs; m->lastMaxRows = max_rows;
+    m->lastBowQ = 0; m->lastBowT = 0;
+    if (d_matches) *d_matches = m->d_out;
+    if (d_nmatches) *d_nmatches = m->d_nout;
+    return SSVIO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+// capi_frame.hip -- the C ABI of include/ssvio_gpu.h, part 4: the steps behind the matcher.
+#include "capi_internal.h"
+
+// =====================================================================================
+// behind the matcher
+static int cam_dev(const ssvio_camera* cam, int w, int h, int stride_px, FrameCam& c)
+{
+    if (!cam) { set_error("null camera"); return SSVIO_ERR_INVALID; }
+    if (w <= 0 || h <= 0 || stride_px < w) { set_error("bad depth image geometry %dx%d stride %d", w, h, stride_px); return SSVIO_ERR_INVALID; }
+    c.cx = cam->cx; c.cy = cam->cy;
+    c.invFx = 1 / cam->fx; c.invFy = 1 / cam->fy;                    // include/Init.h:19-20
+    c.depthScale = cam->depth_scale; c.w = w; c.h = h; c.stridePx = stride_px;
+    return SSVIO_OK;
+}
+
+
+// carve the assembled-list block of the handle into its seven arrays + counts
+static int assemble_outputs(ssvio_matcher* m, int npairs, int maxRows, AssembleArgs& a)
+{
+    const size_t rows = (size_t)npairs * maxRows;
+    const size_t s3 = align256(rows * 12), s2 = align256(rows * 8), sm = align256(rows * 16), sc = align256((size_t)npairs * 8);
+    int rc = grow(m->d_frameOut, m->frameOutCap, 4 * s3 + s2 + 2 * sm + sc, m->stream); if (rc) return rc;
+    uint8_t* p = m->d_frameOut;
+    a.last3d = (float*)p; p += s3; a.cur3d = (float*)p; p += s3; a.edgeLast3d = (float*)p; p += s3; a.edgeCur3d = (float*)p; p += s3;
+    a.cur2d = (float*)p; p += s2; a.preGood = (ssvio_dmatch*)p; p += sm; a.finalGood = (ssvio_dmatch*)p; p += sm; a.counts = (int*)p;
+    return SSVIO_OK;
+}
+
+extern "C" {
+
+int ssvio_get_3d_points(ssvio_matcher* m, const ssvio_keypoint* kps, int n, const uint16_t* depth, int w, int h, int stride_px,
+                        const ssvio_camera* cam, float* out)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    FrameCam c; int rc = cam_dev(cam, w, h, stride_px, c); if (rc) return rc;
+    if (n < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (n == 0) return SSVIO_OK;
+    if (!kps || !depth || !out) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t kb = align256((size_t)n * sizeof(ssvio_keypoint)), db = align256((size_t)h * stride_px * 2);
+    rc = grow(m->d_frameIn, m->frameInCap, kb + db, s); if (rc) return rc;
+    rc = grow(m->d_frameOut, m->frameOutCap, (size_t)n * 12, s); if (rc) return rc;
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, kps, (size_t)n * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn + kb, depth, (size_t)h * stride_px * 2, hipMemcpyHostToDevice, s));
+    {
+        ProfScope p(m->prof, "k_get_3d_points", s);
+        launch_get_3d_points((const ssvio_keypoint*)m->d_frameIn, n, (const uint16_t*)(m->d_frameIn + kb), c, (float*)m->d_frameOut, s);
+    }
+    SSVIO_HIP(hipMemcpyAsync(out, m->d_frameOut, (size_t)n * 12, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_assemble_correspondences(ssvio_matcher* m, const ssvio_dmatch* matches, int nm,
+                                   const ssvio_keypoint* last_kps, int nlast, const uint16_t* last_depth,
+                                   const ssvio_keypoint* cur_kps, int ncur, const uint16_t* cur_depth,
+                                   int w, int h, int stride_px, const ssvio_camera* cam,
+                                   float* last3d, float* cur2d, float* cur3d, ssvio_dmatch* pre_good, int* n_pre,
+                                   float* edge_last3d, float* edge_cur3d, ssvio_dmatch* final_good, int* n_final)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    FrameCam c; int rc = cam_dev(cam, w, h, stride_px, c); if (rc) return rc;
+    if (n_pre) *n_pre = 0;
+    if (n_final) *n_final = 0;
+    if (nm < 0 || nlast < 0 || ncur < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (nm == 0) return SSVIO_OK;                                   // the loop of src/Odometry.cpp:44 does not run
+    if (!matches || !last_kps || !cur_kps || !last_depth || !cur_depth || !last3d || !cur2d || !cur3d || !pre_good || !n_pre ||
+        !edge_last3d || !edge_cur3d || !final_good || !n_final) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    for (int i = 0; i < nm; ++i)
+        if (matches[i].trainIdx < 0 || matches[i].trainIdx >= nlast || matches[i].queryIdx < 0 || matches[i].queryIdx >= ncur) {
+            set_error("match %d (query %d, train %d) is outside the keypoint lists (%d, %d)", i, matches[i].queryIdx, matches[i].trainIdx, ncur, nlast);
+            return SSVIO_ERR_INVALID;
+        }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const int kpStride = std::max(std::max(nlast, ncur), 1);
+    const size_t depthPx = (size_t)h * stride_px;
+    const size_t mb = align256((size_t)nm * 16), kb = align256((size_t)2 * kpStride * sizeof(ssvio_keypoint)), db = align256(2 * depthPx * 2);
+    rc = grow(m->d_frameIn, m->frameInCap, mb + kb + db + 256, s); if (rc) return rc;
+    uint8_t* d_m = m->d_frameIn; uint8_t* d_k = d_m + mb; uint8_t* d_d = d_k + kb; int* d_c = (int*)(d_d + db);   // {nm, ncur, nlast}
+    SSVIO_HIP(hipMemcpyAsync(d_m, matches, (size_t)nm * 16, hipMemcpyHostToDevice, s));
+    if (ncur) SSVIO_HIP(hipMemcpyAsync(d_k, cur_kps, (size_t)ncur * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));       // set 0 = current
+    if (nlast) SSVIO_HIP(hipMemcpyAsync(d_k + (size_t)kpStride * sizeof(ssvio_keypoint), last_kps, (size_t)nlast * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(d_d, cur_depth, depthPx * 2, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(d_d + depthPx * 2, last_depth, depthPx * 2, hipMemcpyHostToDevice, s));
+    const int cnts[3] = {nm, ncur, nlast};
+    SSVIO_HIP(hipMemcpyAsync(d_c, cnts, sizeof cnts, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipStreamSynchronize(s));                             // `cnts` is a stack array
+    AssembleArgs a{};
+    a.matches = (const ssvio_dmatch*)d_m; a.nmatches = d_c; a.maxRows = nm; a.pairs = nullptr;
+    a.kps = (const ssvio_keypoint*)d_k; a.kpStride = kpStride; a.kpCounts = d_c + 1;
+    a.depth = (const uint16_t*)d_d; a.depthFrameStride = depthPx; a.cam = c;
+    rc = assemble_outputs(m, 1, nm, a); if (rc) return rc;
+    {
+        ProfScope p(m->prof, "k_assemble", s);
+        launch_assemble(a, 1, s);
+    }
+    int got[2] = {0, 0};
+    SSVIO_HIP(hipMemcpyAsync(got, a.counts, sizeof got, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    const size_t np = (size_t)got[0], nf = (size_t)got[1];
+    if (np) {
+        SSVIO_HIP(hipMemcpyAsync(last3d, a.last3d, np * 12, hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(cur2d, a.cur2d, np * 8, hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(cur3d, a.cur3d, np * 12, hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(pre_good, a.preGood, np * 16, hipMemcpyDeviceToHost, s));
+    }
+    if (nf) {
+        SSVIO_HIP(hipMemcpyAsync(edge_last3d, a.edgeLast3d, nf * 12, hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(edge_cur3d, a.edgeCur3d, nf * 12, hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipMemcpyAsync(final_good, a.finalGood, nf * 16, hipMemcpyDeviceToHost, s));
+    }
+    SSVIO_HIP(hipStreamSynchronize(s));
+    *n_pre = got[0]; *n_final = got[1];
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_assemble_batch_dev(ssvio_matcher* m, const void* d_matches, const int32_t* d_nmatches, int max_rows,
+                             const int32_t* pairs, int npairs, const void* d_kps, int kp_stride, const int32_t* d_kpcounts,
+                             const void* d_depth, size_t depth_frame_stride, int w, int h, int stride_px,
+                             const ssvio_camera* cam, ssvio_correspondences_dev* out)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    FrameCam c; int rc = cam_dev(cam, w, h, stride_px, c); if (rc) return rc;
+    if (!d_matches || !d_nmatches || !pairs || !d_kps || !d_kpcounts || !d_depth || !out || npairs <= 0 || max_rows <= 0 || kp_stride <= 0 ||
+        depth_frame_stride < (size_t)h * stride_px) { set_error("bad batch arguments"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    rc = upload_pairs(m, pairs, npairs); if (rc) return rc;
+    AssembleArgs a{};
+    a.matches = (const ssvio_dmatch*)d_matches; a.nmatches = d_nmatches; a.maxRows = max_rows; a.pairs = m->d_pairs;
+    a.kps = (const ssvio_keypoint*)d_kps; a.kpStride = kp_stride; a.kpCounts = d_kpcounts;
+    a.depth = (const uint16_t*)d_depth; a.depthFrameStride = depth_frame_stride; a.cam = c;
+    rc = assemble_outputs(m, npairs, max_rows, a); if (rc) return rc;
+    {
+        ProfScope p(m->prof, "k_assemble", m->stream);
+        launch_assemble(a, npairs, m->stream);
+    }
+    out->last3d = a.last3d; out->cur2d = a.cur2d; out->cur3d = a.cur3d; out->pre_good = a.preGood;
+    out->edge_last3d = a.edgeLast3d; out->edge_cur3d = a.edgeCur3d; out->final_good = a.finalGood; out->counts = a.counts;
+    return SSVIO_OK;
+}
+
+// index map over a DMatch list on the device: table[key] = first position (0xFFFFFFFF = none)
+static int first_index_table(ssvio_matcher* m, const ssvio_dmatch* d_v, int n, int useTrain, int tableSize)
+{
+    hipStream_t s = m->stream;
+    int rc = grow(m->d_table, m->tableCap, (size_t)std::max(tableSize, 1), s); if (rc) return rc;
+    SSVIO_HIP(hipMemsetAsync(m->d_table, 0xFF, (size_t)std::max(tableSize, 1) * 4, s));
+    ProfScope p(m->prof, "k_first_index", s);
+    launch_first_index(d_v, n, useTrain, m->d_table, tableSize, s);
+    return SSVIO_OK;
+}
+
+int ssvio_track_map_points(ssvio_matcher* m, const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, int ncur,
+                           ssvio_dmatch* out, int cap, int* n)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (n) *n = 0;
+    if (nlast < 0 || ncur < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (nlast == 0 || ncur == 0) return SSVIO_OK;                    // no pair can meet: last_match_vec becomes empty (src/Map.cpp:121-122)
+    if (!last || !cur || !out || !n) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    if (cap < nlast) { set_error("output capacity %d < %d", cap, nlast); return SSVIO_ERR_CAPACITY; }
+    int maxKey = -1;                                                 // the map covers the keys the join can ask for
+    for (int i = 0; i < nlast; ++i) maxKey = std::max(maxKey, last[i].queryIdx);
+    if (maxKey < 0) return SSVIO_OK;
+    if (maxKey >= (1 << 28)) { set_error("queryIdx %d too large for an index map", maxKey); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t lb = align256((size_t)nlast * 16), cb = align256((size_t)ncur * 16);
+    int rc = grow(m->d_frameIn, m->frameInCap, lb + cb, s); if (rc) return rc;
+    rc = grow(m->d_out, m->outCap, (size_t)nlast, s); if (rc) return rc;
+    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, last, (size_t)nlast * 16, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn + lb, cur, (size_t)ncur * 16, hipMemcpyHostToDevice, s));
+    rc = first_index_table(m, (const ssvio_dmatch*)(m->d_frameIn + lb), ncur, 1, maxKey + 1); if (rc) return rc;
+    {
+        ProfScope p(m->prof, "k_track", s);
+        launch_track((const ssvio_dmatch*)m->d_frameIn, nlast, (const ssvio_dmatch*)(m->d_frameIn + lb), m->d_table, maxKey + 1, m->d_out, m->d_nout, s);
+    }
+    int cnt = 0;
+    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+    *n = cnt;
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_in_match_vec(ssvio_matcher* m, const ssvio_dmatch* vec, int n, int nkp, int32_t* out)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (n < 0 || nkp < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (nkp == 0) return SSVIO_OK;
+    if (!out || (n > 0 && !vec)) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    int rc = grow(m->d_frameIn, m->frameInCap, (size_t)std::max(n, 1) * 16, s); if (rc) return rc;
+    if (n) SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, vec, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    rc = first_index_table(m, (const ssvio_dmatch*)m->d_frameIn, n, 0, nkp); if (rc) return rc;
+    SSVIO_HIP(hipMemcpyAsync(out, m->d_table, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));    // 0xFFFFFFFF reads as -1
+    SSVIO_HIP(hipStreamSynchronize(s));
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+}  // extern "C"
+
+extern "C" int ssvio_rgb_cloud(ssvio_matcher* m, const uint16_t* depth, int depth_stride_px, const uint8_t* bgr, int bgr_stride,
+                               int w, int h, const ssvio_camera* cam, double depth_scale, void* out)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    FrameCam c; int rc = cam_dev(cam, w, h, depth_stride_px, c); if (rc) return rc;
+    if (!depth || !bgr || !out || bgr_stride < 3 * w) { set_error("bad cloud arguments"); return SSVIO_ERR_INVALID; }
+    if ((size_t)w * h > ((size_t)1 << 28)) { set_error("image too large"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t db = align256((size_t)h * depth_stride_px * 2), cb = align256((size_t)h * bgr_stride), ob = (size_t)w * h * 32;
+    rc = grow(m->d_frameIn, m->frameInCap, db + cb, s); if (rc) return rc;
+    rc = grow(m->d_frameOut, m->frameOutCap, ob, s); if (rc) return rc;
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, depth, (size_t)h * depth_stride_px * 2, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(m->d_frameIn + db, bgr, (size_t)h * bgr_stride, hipMemcpyHostToDevice, s));
+    {
+        ProfScope p(m->prof, "k_rgb_cloud", s);
+        launch_rgb_cloud((const uint16_t*)m->d_frameIn, depth_stride_px, m->d_frameIn + db, bgr_stride, w, h, c.cx, c.cy, c.invFx, c.invFy,
+                         depth_scale, m->d_frameOut, s);
+    }
+    SSVIO_HIP(hipMemcpyAsync(out, m->d_frameOut, ob, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    m->prof.resolve();
+    return SSVIO_OK;
+}

@@ -1,0 +1,65 @@
+// capi_internal.h -- shared by the translation units of the C ABI (capi*.hip): the matcher handle and small host helpers.
+#pragma once
+#include "common.h"
+#include "match.h"
+#include <algorithm>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+namespace ssvio {
+int pick_device(int device);                       // SSVIO_OK, SSVIO_ERR_NOGPU or SSVIO_ERR_INVALID (capi.hip)
+int prof_out(KernelProfiler& p, const char** names, double* total_ms, int32_t* launches, int cap, int* count);   // capi.hip
+template <typename T> inline void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+template <typename T> inline void hfree(T*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } }
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace ssvio
+
+using namespace ssvio;
+
+struct ssvio_matcher {
+    int device = 0;
+    int threshold = 50; float nnRatio = 0.6f;
+    hipStream_t own = nullptr, stream = nullptr;
+    uint8_t* d_q = nullptr; size_t qRows = 0;
+    uint8_t* d_t = nullptr; size_t tRows = 0;
+    int* d_counts2 = nullptr;            // {nq, nt} of the single-pair entry points
+    uint2* d_partial = nullptr; size_t partialCap = 0;
+    uint2* d_partialRev = nullptr; size_t partialRevCap = 0;
+    ssvio_dmatch* d_out = nullptr; size_t outCap = 0;
+    int32_t* d_raw = nullptr; size_t rawCap = 0;
+    int* d_nout = nullptr; size_t noutCap = 0;
+    int* d_pairs = nullptr; size_t pairsCap = 0;
+    double* d_p3d = nullptr; size_t p3dCap = 0; double* d_p2d = nullptr; size_t p2dCap = 0;     // MatchByProject inputs
+    ssvio_dmatch* d_cand = nullptr; size_t candCap = 0; int* d_keep = nullptr; size_t keepCap = 0;
+    // MatchByDBoW: per-feature transform results (query rows first, then train rows) and the grouped-match scratch
+    int32_t* d_bowWord = nullptr; size_t bowWordCap = 0; int32_t* d_bowNode = nullptr; size_t bowNodeCap = 0;
+    double* d_bowWeight = nullptr; size_t bowWeightCap = 0; int32_t* d_gnode = nullptr; size_t gnodeCap = 0;
+    int32_t* d_keepNode = nullptr; size_t keepNodeCap = 0;
+    int32_t* d_sortIdx = nullptr; size_t sortIdxCap = 0; int32_t* d_sortNode = nullptr; size_t sortNodeCap = 0;
+    int lastBowQ = 0, lastBowT = 0;
+    // behind the matcher (f2, f3)
+    uint8_t* d_frameIn = nullptr; size_t frameInCap = 0;      // uploaded matches / keypoints / depth of the host entry points
+    uint8_t* d_frameOut = nullptr; size_t frameOutCap = 0;    // assembled lists
+    uint32_t* d_table = nullptr; size_t tableCap = 0;
+    std::vector<uint8_t> stageQ, stageT;              // packed copies of strided descriptor rows
+    std::vector<int32_t> h_pairs;                     // what d_pairs holds (an unchanged pair list is not uploaded again)
+    KernelProfiler prof; std::string profOnly;
+    int lastPairs = 0, lastMaxRows = 0;
+};
+
+// grows a device array of the handle (never shrinks); waits for the stream first: queued work may still use the old block
+template <typename T> inline int grow(T*& p, size_t& cap, size_t need, hipStream_t s)
+{
+    if (need <= cap) return SSVIO_OK;
+    SSVIO_HIP(hipStreamSynchronize(s));
+    dfree(p);
+    need += need / 4;
+    SSVIO_HIP(hipMalloc(&p, need * sizeof(T)));
+    cap = need;
+    return SSVIO_OK;
+}
+
+inline int mt_check(ssvio_matcher* m) { if (!m) { set_error("null matcher handle"); return SSVIO_ERR_INVALID; } return SSVIO_OK; }
+int upload_rows(uint8_t* dst, const uint8_t* src, int n, int stride, std::vector<uint8_t>& staging, hipStream_t s);   // capi_match.hip
+int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs);                                                   // capi_match.hip

@@ -1,0 +1,307 @@
+// capi_match.hip -- the C ABI of include/ssvio_gpu.h, part 2: the matcher handle (class FeatureMatching): brute-force / 2-NN /
+// cross-check matching, MatchByProject, the batched device-resident entry points.
+#include "capi_internal.h"
+
+// descriptor rows host -> device.  Continuous rows (the usual cv::Mat) are one copy; strided rows are packed on the
+// host first: a 2-D copy of 32-byte rows costs a transfer per row (18 ms for 1000 rows on this stack).
+int upload_rows(uint8_t* dst, const uint8_t* src, int n, int stride, std::vector<uint8_t>& staging, hipStream_t s)
+{
+    if (n <= 0) return SSVIO_OK;
+    if (stride == 32) { SSVIO_HIP(hipMemcpyAsync(dst, src, (size_t)n * 32, hipMemcpyHostToDevice, s)); return SSVIO_OK; }
+    staging.resize((size_t)n * 32);
+    for (int i = 0; i < n; ++i) memcpy(staging.data() + (size_t)i * 32, src + (size_t)i * stride, 32);
+    SSVIO_HIP(hipMemcpyAsync(dst, staging.data(), (size_t)n * 32, hipMemcpyHostToDevice, s));
+    return SSVIO_OK;
+}
+
+// choose how many pieces the train set is cut into so that the launch has >= ~2048 workgroups (two per SIMD)
+static void pick_chunks(int maxQ, int maxT, int npairs, int& nChunks, int& chunkRows)
+{
+    static const int forcedRows = [] { const char* e = getenv("SSVIO_MATCH_CHUNKROWS"); return e ? atoi(e) : 0; }();   // tuning knob
+    const int R = knn2_queries_per_lane(maxQ);
+    const long qBlocks = (long)((maxQ + 256 * R - 1) / (256 * R)) * npairs;
+    long want = (2048 + qBlocks - 1) / qBlocks;
+    const long maxChunks = std::max(1, (maxT + 127) / 128);
+    want = std::min<long>(std::min<long>(want, maxChunks), 64);
+    nChunks = (int)std::max<long>(want, 1);
+    chunkRows = ((maxT + nChunks - 1) / nChunks + 127) / 128 * 128;
+    if (forcedRows >= 128) chunkRows = forcedRows / 128 * 128;
+    nChunks = std::max(1, (maxT + chunkRows - 1) / chunkRows);
+}
+
+// the pair list of the batched entry points, on the device (an unchanged list is not uploaded again)
+int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs)
+{
+    if (m->h_pairs.size() == (size_t)npairs * 2 && memcmp(m->h_pairs.data(), pairs, (size_t)npairs * 2 * sizeof(int32_t)) == 0) return SSVIO_OK;
+    int rc = grow(m->d_pairs, m->pairsCap, (size_t)npairs * 2, m->stream); if (rc) return rc;
+    SSVIO_HIP(hipStreamSynchronize(m->stream));    // earlier launches may still read the old list
+    m->h_pairs.assign(pairs, pairs + (size_t)npairs * 2);
+    SSVIO_HIP(hipMemcpyAsync(m->d_pairs, m->h_pairs.data(), (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    return SSVIO_OK;
+}
+
+// shared driver: descriptors on the device; pairs == nullptr means the single pair (0,0)
+static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
+                     const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts,
+                     const int* d_pairs, int npairs, int maxQ, int maxT, int mode)
+{
+    hipStream_t s = m->stream;
+    const int maxRows = std::max(maxQ, maxT);
+    int nChunks, chunkRows;
+    pick_chunks(maxQ, maxT, npairs, nChunks, chunkRows);
+    int rc = grow(m->d_partial, m->partialCap, (size_t)npairs * nChunks * maxRows, s); if (rc) return rc;
+    rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
+    if (mode == 3) { rc = grow(m->d_raw, m->rawCap, (size_t)npairs * 3 * maxRows, s); if (rc) return rc; }
+    else { rc = grow(m->d_out, m->outCap, (size_t)npairs * maxRows, s); if (rc) return rc; }
+    MatchArgs a{};
+    a.qdesc = (const uint4*)d_qdesc; a.tdesc = (const uint4*)d_tdesc;
+    a.qSetStrideRows = qStrideRows; a.tSetStrideRows = tStrideRows;
+    a.qcounts = d_qcounts; a.tcounts = d_tcounts; a.pairs = d_pairs; a.swap = 0;
+    a.nChunks = nChunks; a.chunkRows = chunkRows; a.partial = m->d_partial; a.maxRows = maxRows;
+    {
+        ProfScope p(m->prof, "k_hamming_knn2", s);
+        launch_knn2(a, maxQ, npairs, s);
+    }
+    FinalizeArgs f{};
+    f.partial = m->d_partial; f.nChunks = nChunks; f.maxRows = maxRows;
+    f.qcounts = d_qcounts; f.tcounts = d_tcounts; f.pairs = d_pairs;
+    f.mode = mode; f.threshold = m->threshold; f.nnRatio = m->nnRatio;
+    f.out = m->d_out; f.nout = m->d_nout; f.raw = m->d_raw;
+    if (mode == SSVIO_MODE_CROSSCHECK) {
+        int nChunksR, chunkRowsR;
+        pick_chunks(maxT, maxQ, npairs, nChunksR, chunkRowsR);
+        rc = grow(m->d_partialRev, m->partialRevCap, (size_t)npairs * nChunksR * maxRows, s); if (rc) return rc;
+        MatchArgs r = a;
+        r.qdesc = (const uint4*)d_tdesc; r.tdesc = (const uint4*)d_qdesc;
+        r.qSetStrideRows = tStrideRows; r.tSetStrideRows = qStrideRows;
+        r.qcounts = d_tcounts; r.tcounts = d_qcounts; r.swap = 1;
+        r.nChunks = nChunksR; r.chunkRows = chunkRowsR; r.partial = m->d_partialRev;
+        {
+            ProfScope p(m->prof, "k_hamming_knn2", s);
+            launch_knn2(r, maxT, npairs, s);
+        }
+        f.partialRev = m->d_partialRev; f.nChunksRev = nChunksR;
+    }
+    {
+        ProfScope p(m->prof, "k_match_finalize", s);
+        launch_finalize(f, npairs, maxQ, maxT, s);
+    }
+    m->lastPairs = npairs; m->lastMaxRows = maxRows;
+    return SSVIO_OK;
+}
+
+// host-pointer single pair
+static int match_host(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, int mode,
+                      ssvio_dmatch* out, int cap, int* n, int32_t* idx, int32_t* d1, int32_t* d2)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (nq < 0 || nt < 0) { set_error("negative row count"); return SSVIO_ERR_INVALID; }
+    if (n) *n = 0;
+    if (!(nq > 0 && nt > 0)) return SSVIO_OK;                          // src/FeatureMatching.cpp:25-27
+    if (!q || !t) { set_error("null descriptor pointer"); return SSVIO_ERR_INVALID; }
+    if (qstride < 32 || tstride < 32) { set_error("descriptor stride < 32"); return SSVIO_ERR_INVALID; }
+    if (nt > (1 << 23) || nq > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
+    if (mode != 3 && cap < nq) { set_error("output capacity %d < %d query rows", cap, nq); return SSVIO_ERR_CAPACITY; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
+    int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
+    rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
+    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
+    rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
+    const int counts[2] = {nq, nt};
+    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipStreamSynchronize(s));                                // `counts` is a stack array
+    rc = match_run(m, m->d_q, 0, m->d_counts2, m->d_t, 0, m->d_counts2 + 1, nullptr, 1, nq, nt, mode);
+    if (rc) return rc;
+    const int maxRows = std::max(nq, nt);
+    if (mode == 3) {
+        std::vector<int32_t> raw((size_t)3 * maxRows);
+        SSVIO_HIP(hipMemcpyAsync(raw.data(), m->d_raw, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < nq; ++i) { if (idx) idx[i] = raw[i]; if (d1) d1[i] = raw[maxRows + i]; if (d2) d2[i] = raw[2 * (size_t)maxRows + i]; }
+    } else {
+        int cnt = 0;
+        SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+        SSVIO_HIP(hipStreamSynchronize(s));
+        if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+        if (n) *n = cnt;
+    }
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+extern "C" {
+
+int ssvio_matcher_create(int threshold, float nn_ratio, int device, ssvio_matcher** out)
+{
+    if (!out) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    *out = nullptr;
+    const int rc = pick_device(device);
+    if (rc) return rc;
+    SSVIO_HIP(hipSetDevice(device));
+    ssvio_matcher* m = new ssvio_matcher();
+    m->device = device; m->threshold = threshold; m->nnRatio = nn_ratio;
+    if (hipStreamCreateWithFlags(&m->own, hipStreamNonBlocking) != hipSuccess || hipMalloc(&m->d_counts2, 2 * sizeof(int)) != hipSuccess) {
+        set_error("cannot create HIP stream / allocate"); delete m; return SSVIO_ERR_HIP;
+    }
+    m->stream = m->own;
+    *out = m;
+    return SSVIO_OK;
+}
+
+void ssvio_matcher_destroy(ssvio_matcher* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    m->prof.resolve(); m->prof.destroy();
+    dfree(m->d_q); dfree(m->d_t); dfree(m->d_counts2); dfree(m->d_partial); dfree(m->d_partialRev);
+    dfree(m->d_out); dfree(m->d_raw); dfree(m->d_nout); dfree(m->d_pairs);
+    dfree(m->d_p3d); dfree(m->d_p2d); dfree(m->d_cand); dfree(m->d_keep);
+    dfree(m->d_bowWord); dfree(m->d_bowNode); dfree(m->d_bowWeight); dfree(m->d_gnode); dfree(m->d_keepNode); dfree(m->d_sortIdx); dfree(m->d_sortNode);
+    dfree(m->d_frameIn); dfree(m->d_frameOut); dfree(m->d_table);
+    if (m->own) (void)hipStreamDestroy(m->own);
+    delete m;
+}
+
+int ssvio_matcher_set_stream(ssvio_matcher* m, void* hip_stream)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(m->device));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    m->stream = hip_stream ? (hipStream_t)hip_stream : m->own;
+    return SSVIO_OK;
+}
+
+int ssvio_matcher_profile_only(ssvio_matcher* m, const char* kernel)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    m->profOnly = kernel ? kernel : "";
+    m->prof.only = m->profOnly.empty() ? nullptr : m->profOnly.c_str();
+    return SSVIO_OK;
+}
+
+int ssvio_matcher_set_profiling(ssvio_matcher* m, int enable)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(m->device));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    m->prof.clear();
+    m->prof.enabled = enable != 0;
+    return SSVIO_OK;
+}
+
+int ssvio_matcher_kernel_times(ssvio_matcher* m, const char** names, double* total_ms, int32_t* launches, int cap, int* count)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(m->device));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    return prof_out(m->prof, names, total_ms, launches, cap, count);
+}
+
+int ssvio_match_bruteforce(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
+                           ssvio_dmatch* out, int cap, int* n)
+{ return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_BRUTEFORCE, out, cap, n, nullptr, nullptr, nullptr); }
+
+int ssvio_match_knn2_ratio(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
+                           ssvio_dmatch* out, int cap, int* n)
+{ return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_KNN2_RATIO, out, cap, n, nullptr, nullptr, nullptr); }
+
+int ssvio_match_crosscheck(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
+                           ssvio_dmatch* out, int cap, int* n)
+{ return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_CROSSCHECK, out, cap, n, nullptr, nullptr, nullptr); }
+
+int ssvio_match_knn2_raw(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
+                         int32_t* idx, int32_t* d1, int32_t* d2)
+{ return match_host(m, q, nq, qstride, t, nt, tstride, 3, nullptr, 0, nullptr, idx, d1, d2); }
+
+int ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, int nq, int qstride,
+                        const double* p2d, const uint8_t* t, int nt, int tstride, double radian,
+                        const double* K, const double* R, const double* tr, ssvio_dmatch* out, int cap, int* n)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (n) *n = 0;
+    if (nq < 0 || nt < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (nq == 0) return SSVIO_OK;                                   // the loop of src/FeatureMatching.cpp:135 does not run
+    if (!p3d || !q || !K || !R || !tr || !n || (nt > 0 && (!p2d || !t))) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    if (qstride < 32 || (nt > 0 && tstride < 32)) { set_error("descriptor stride < 32"); return SSVIO_ERR_INVALID; }
+    if (nt > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
+    if (cap < nq) { set_error("output capacity %d < %d reference points", cap, nq); return SSVIO_ERR_CAPACITY; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
+    int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
+    rc = grow(m->d_t, tcap, (size_t)std::max(nt, 1) * 32, s); if (rc) return rc; m->tRows = tcap / 32;
+    rc = grow(m->d_p3d, m->p3dCap, (size_t)nq * 3, s); if (rc) return rc;
+    rc = grow(m->d_p2d, m->p2dCap, (size_t)std::max(nt, 1) * 2, s); if (rc) return rc;
+    rc = grow(m->d_cand, m->candCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_keep, m->keepCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_out, m->outCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
+    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
+    SSVIO_HIP(hipMemcpyAsync(m->d_p3d, p3d, (size_t)nq * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (nt > 0) {
+        rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
+        SSVIO_HIP(hipMemcpyAsync(m->d_p2d, p2d, (size_t)nt * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    ProjectArgs a{};
+    a.p3d = m->d_p3d; a.qdesc = (const uint4*)m->d_q; a.nq = nq; a.p2d = m->d_p2d; a.tdesc = (const uint4*)m->d_t; a.nt = nt;
+    a.radian = radian;
+    for (int i = 0; i < 9; ++i) { a.K[i] = K[i]; a.R[i] = R[i]; }
+    for (int i = 0; i < 3; ++i) a.t[i] = tr[i];
+    a.threshold = m->threshold; a.nnRatio = m->nnRatio;
+    a.cand = m->d_cand; a.keep = m->d_keep; a.out = m->d_out; a.nout = m->d_nout;
+    {
+        ProfScope p(m->prof, "k_match_project", s);
+        launch_project(a, s);
+    }
+    int cnt = 0;
+    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipStreamSynchronize(s));
+    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+    *n = cnt;
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_rows, int max_rows, const int32_t* d_counts,
+                          const int32_t* pairs, int npairs, int mode, const void** d_matches, const int32_t** d_nmatches)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (!d_desc || !d_counts || !pairs || npairs <= 0 || max_rows <= 0 || set_stride_rows < max_rows) { set_error("bad batch arguments"); return SSVIO_ERR_INVALID; }
+    if (mode < 0 || mode > 2) { set_error("mode must be 0..2"); return SSVIO_ERR_INVALID; }
+    if (max_rows > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    int rc = SSVIO_OK;
+    rc = upload_pairs(m, pairs, npairs); if (rc) return rc;
+    rc = match_run(m, (const uint8_t*)d_desc, set_stride_rows, d_counts, (const uint8_t*)d_desc, set_stride_rows, d_counts,
+                   m->d_pairs, npairs, max_rows, max_rows, mode);
+    if (rc) return rc;
+    if (d_matches) *d_matches = m->d_out;
+    if (d_nmatches) *d_nmatches = m->d_nout;
+    return SSVIO_OK;
+}
+
+int ssvio_matcher_sync(ssvio_matcher* m)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    SSVIO_HIP(hipSetDevice(m->device));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_match_batch_fetch(ssvio_matcher* m, int npairs, int max_rows, ssvio_dmatch* out, int32_t* n)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (npairs != m->lastPairs || max_rows != m->lastMaxRows || !n) { set_error("fetch does not match the last batch call"); return SSVIO_ERR_INVALID; }
+    SSVIO_HIP(hipSetDevice(m->device));
+    SSVIO_HIP(hipMemcpyAsync(n, m->d_nout, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if (out) SSVIO_HIP(hipMemcpyAsync(out, m->d_out, (size_t)npairs * max_rows * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost, m->stream));
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    return SSVIO_OK;
+}
+
+}  // extern "C"
