@@ -3,9 +3,11 @@
 //   Odometry::OptimizeTransform  the two filter loops, src/Odometry.cpp:44-64 and :94-108
 //   Map::TrackMapPoints          include/Map.h, src/Map.cpp:100-123
 //   Map::InMatchVec              src/Map.cpp:151-162
+//   Map::ManageMapPoints         the loop's decisions and values, src/Map.cpp:125-149 (with Frame::GetMapPointID, src/Frame.cpp:138-147)
 // Free functions over a FeatureMatching adapter (they share its handle and stream); INTEGRATION.md shows where
 // the reference's member functions would call them.
 #pragma once
+#include <utility>
 #include <vector>
 #include "FeatureMatching.h"
 
@@ -92,6 +94,25 @@ inline bool InMatchVec(FeatureMatching& fm, const std::vector<cv::DMatch>& last_
     match_num.assign((size_t)(nkp > 0 ? nkp : 0), -1);
     if (nkp <= 0) return true;
     return ssvio_in_match_vec(fm.handle(), (const ssvio_dmatch*)last_match_vec.data(), (int)last_match_vec.size(), nkp, match_num.data()) == SSVIO_OK;
+}
+
+// The loop of Map::ManageMapPoints(key_frame, last_match_vec), src/Map.cpp:128-148, in one call.  world_trans points at the
+// 16 floats of key_frame->GetAbsPose().inverse() (Eigen::Matrix4f::data()); observed is GetKeyFrames(-1)->GetObserve().
+// Afterwards, for i in order: match_num[i] == -1 -> make_shared<MapPoint>(new_point[i]) (:135); else -> _map_point_vec[map_point[i]] (:143).
+inline bool ManageMapPoints(FeatureMatching& fm, const std::vector<cv::KeyPoint>& kps, const cv::Mat& depth, const ssvio_camera& cam,
+                            const float* world_trans, const std::vector<cv::DMatch>& last_match_vec,
+                            const std::vector<std::pair<int, int>>& observed,
+                            std::vector<int>& match_num, std::vector<int>& map_point, std::vector<Point3f>& new_point)
+{
+    static_assert(sizeof(std::pair<int, int>) == 8, "std::pair<int, int> layout");
+    const size_t n = kps.size();
+    match_num.assign(n, -1); map_point.assign(n, -1); new_point.assign(n, Point3f{0.f, 0.f, 0.f});
+    if (n == 0) return true;
+    return ssvio_manage_map_points(fm.handle(), (const ssvio_keypoint*)kps.data(), (int)n, (const uint16_t*)depth.ptr(0),
+                                   depth.cols, depth.rows, (int)(depth.step / 2), &cam, world_trans,
+                                   (const ssvio_dmatch*)last_match_vec.data(), (int)last_match_vec.size(),
+                                   (const int32_t*)observed.data(), (int)observed.size(),
+                                   match_num.data(), map_point.data(), &new_point[0].x) == SSVIO_OK;
 }
 
 }  // namespace ssvio

@@ -274,6 +274,21 @@ int  ssvio_track_map_points(ssvio_matcher* m, const ssvio_dmatch* last, int nlas
 /* Map::InMatchVec(i, vec), src/Map.cpp:151-162, for i = 0..nkp-1 (the loop of ManageMapPoints, :128-131):
  * out[i] = index of the first match with queryIdx == i, or -1 */
 int  ssvio_in_match_vec(ssvio_matcher* m, const ssvio_dmatch* vec, int n, int nkp, int32_t* out);
+/* Map::ManageMapPoints(key_frame, last_match_vec), src/Map.cpp:125-149, with Frame::GetMapPointID, src/Frame.cpp:138-147:
+ * the decisions and values of its loop for keypoints i = 0..nkp-1 (MapPoint objects and the SetObserve bookkeeping stay
+ * with the caller, who walks the three arrays in order of i):
+ *   match_num[i] = InMatchVec(i, last_match_vec) (:130);
+ *   match_num[i] == -1, a new map point (:131-140): world[i][3] = R * Get3DPoint(i) + t, R and t from world_trans =
+ *     key_frame->GetAbsPose().inverse() (:127), 16 floats as Eigen::Matrix4f::data() holds them (column-major);
+ *     map_point[i] = -1;
+ *   otherwise (:141-147): map_point[i] = the id GetKeyFrames(-1)->GetMapPointID(last_match_vec[match_num[i]].queryIdx)
+ *     returns, i.e. .first of the first pair of obs whose .second is that point id; -1 where the reference finds none
+ *     (it then runs off the end of a non-void function); world[i] = 0.
+ * obs[nobs][2] = that key frame's _observed_mappid_pid_vec as {map_point_id, point_id} (std::pair<int, int> layout).
+ * Both linear searches are index maps here.  Float order: (R(r,0) x + (R(r,1) y + R(r,2) z)) + t_r, no contraction. */
+int  ssvio_manage_map_points(ssvio_matcher* m, const ssvio_keypoint* kps, int nkp, const uint16_t* depth, int w, int h, int stride_px,
+                             const ssvio_camera* cam, const float* world_trans, const ssvio_dmatch* last_match_vec, int nm,
+                             const int32_t* obs, int nobs, int32_t* match_num, int32_t* map_point, float* world);
 
 /* ---- per-pixel cloud (first half) ---------------------------------------------------------- */
 /* The cloud loop of XtionCamera::GrabImage, driver/Xtion_Driver.cpp:219-229, over GetRGB3DPoint (:138-162): one

@@ -6,6 +6,8 @@
  *   src/Odometry.cpp:94-108     ICP edge list / _final_good_match      -> orc_assemble_correspondences, second list
  *   src/Map.cpp:100-123         Map::TrackMapPoints                    -> orc_track_map_points
  *   src/Map.cpp:151-162         Map::InMatchVec (for every keypoint)   -> orc_in_match_vec
+ *   src/Map.cpp:125-149         Map::ManageMapPoints (decisions + values) with Frame::GetMapPointID, src/Frame.cpp:138-147
+ *                                                                      -> orc_manage_map_points
  *   driver/Xtion_Driver.cpp:138-162, :219-229  XtionCamera::GetRGB3DPoint over the frame -> orc_rgb_cloud (f4, first half)
  *   All float arithmetic is single precision, evaluated left to right, no contraction.
  */
@@ -83,6 +85,43 @@ void orc_in_match_vec(const orc_dmatch* vec, int n, int nkp, int32_t* out)
     for (int i = 0; i < nkp; ++i) {
         out[i] = -1;
         for (int j = 0; j < n; ++j) if (vec[j].queryIdx == i) { out[i] = j; break; }
+    }
+}
+
+/* Map::ManageMapPoints, src/Map.cpp:125-149, for every keypoint i of the key frame -- the decisions and values of
+ * the loop; creating MapPoint objects and the SetObserve bookkeeping stay with the caller.
+ *   match_num[i] = InMatchVec(i, last_match_vec)                                                         (:130)
+ *   match_num[i] == -1 (a new map point, :131-140): world[i] = R * Get3DPoint(i) + t with R, t the upper 3x4 of
+ *       world_trans = GetAbsPose().inverse() (:127, :133-136), map_point[i] = -1
+ *   otherwise (:141-147): map_point[i] = GetKeyFrames(-1)->GetMapPointID(last_match_vec[match_num].queryIdx)
+ *       = .first of the FIRST observation pair whose .second is that id (src/Frame.cpp:138-147).  The reference runs
+ *       off the end of a non-void function when no pair has it (undefined there): -1 here.  world[i] = 0.
+ * world_trans: 16 floats in Eigen::Matrix4f's own (column-major) order, element (r, c) at [r + 4 c].
+ * Canonical float order (Eigen's fixed-size 3-term reduction splits 1 + 2): out_r = (R(r,0) x + (R(r,1) y + R(r,2) z)) + t_r,
+ * single precision, no contraction (the reference is built -O3 for baseline x86-64: no FMA).
+ * obs: the key frame's _observed_mappid_pid_vec as int32 pairs {map_point_id, point_id} (include/Frame.h). */
+void orc_manage_map_points(const orc_keypoint* kps, int nkp, const uint16_t* depth, int depth_stride_px, const float cam[5],
+                           const float world_trans[16], const orc_dmatch* last_match_vec, int nm,
+                           const int32_t* obs, int nobs, int32_t* match_num, int32_t* map_point, float* world)
+{
+    orc_in_match_vec(last_match_vec, nm, nkp, match_num);
+    for (int i = 0; i < nkp; ++i) {
+        map_point[i] = -1;
+        world[3 * i] = world[3 * i + 1] = world[3 * i + 2] = 0.f;
+        if (match_num[i] == -1) {
+            float p[3];
+            orc_get_3d_point(kps, i, depth, depth_stride_px, cam, p);                          /* :133 */
+            for (int r = 0; r < 3; ++r) {
+                const float a0 = world_trans[r] * p[0], a1 = world_trans[r + 4] * p[1], a2 = world_trans[r + 8] * p[2];
+                const float tail = a1 + a2;
+                const float dot = a0 + tail;
+                world[3 * i + r] = dot + world_trans[r + 12];                                  /* :135-136 */
+            }
+        } else {
+            const int point_id = last_match_vec[match_num[i]].queryIdx;                        /* :143 */
+            for (int k = 0; k < nobs; ++k)                                                     /* src/Frame.cpp:140-146 */
+                if (obs[2 * k + 1] == point_id) { map_point[i] = obs[2 * k]; break; }
+        }
     }
 }
 

@@ -84,6 +84,7 @@ def lib():
         L.orc_assemble_correspondences.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp] + [vp] * 9
         L.orc_track_map_points.restype = i32; L.orc_track_map_points.argtypes = [vp, i32, vp, i32, vp]
         L.orc_in_match_vec.argtypes = [vp, i32, i32, vp]
+        L.orc_manage_map_points.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp]
         L.orc_rgb_cloud.argtypes = [vp, i32, vp, i32, i32, i32, f32, f32, f32, f32, C.c_double, vp]
         _lib = L
     return _lib
@@ -418,6 +419,19 @@ def in_match_vec(vec, nkp):
     out = np.zeros(nkp, np.int32)
     lib().orc_in_match_vec(_p(vec), len(vec), nkp, _p(out))
     return out
+
+
+def manage_map_points(kps, depth, cam, world_trans, last_match_vec, obs):
+    """Map::ManageMapPoints (src/Map.cpp:125-149): (match_num, map_point, world) per keypoint; world_trans is the 4x4
+    GetAbsPose().inverse() (any array-like, row = matrix row), obs the previous key frame's (map_point_id, point_id) pairs"""
+    kps = np.ascontiguousarray(kps, KP_DTYPE); depth = np.ascontiguousarray(depth, np.uint16); cam = np.ascontiguousarray(cam, np.float32)
+    T = np.ascontiguousarray(np.asarray(world_trans, np.float32).reshape(4, 4).T)           # Eigen's column-major storage
+    v = np.ascontiguousarray(last_match_vec, DM_DTYPE); obs = np.ascontiguousarray(obs, np.int32).reshape(-1, 2)
+    n = len(kps)
+    match_num = np.zeros(n, np.int32); map_point = np.zeros(n, np.int32); world = np.zeros((n, 3), np.float32)
+    lib().orc_manage_map_points(_p(kps), n, _p(depth), depth.shape[1], _p(cam), _p(T), _p(v), len(v), _p(obs), len(obs),
+                                _p(match_num), _p(map_point), _p(world))
+    return match_num, map_point, world
 
 
 CLOUD_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("w", "<f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"), ("a", "u1"),

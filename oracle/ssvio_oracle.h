@@ -119,6 +119,9 @@ void orc_assemble_correspondences(const orc_dmatch* matches, int nm,
                                   float* edge_last3d, float* edge_cur3d, orc_dmatch* final_good, int* n_final); /* src/Odometry.cpp:44-64,94-108 */
 int  orc_track_map_points(const orc_dmatch* last, int nlast, const orc_dmatch* cur, int ncur, orc_dmatch* out); /* src/Map.cpp:100-123 */
 void orc_in_match_vec(const orc_dmatch* vec, int n, int nkp, int32_t* out);              /* src/Map.cpp:151-162 */
+void orc_manage_map_points(const orc_keypoint* kps, int nkp, const uint16_t* depth, int depth_stride_px, const float cam[5],
+                           const float world_trans[16], const orc_dmatch* last_match_vec, int nm,
+                           const int32_t* obs, int nobs, int32_t* match_num, int32_t* map_point, float* world); /* src/Map.cpp:125-149, src/Frame.cpp:138-147 */
 void orc_rgb_cloud(const uint16_t* depth, int depth_stride_px, const uint8_t* bgr, int bgr_stride, int w, int h,
                    float cx, float cy, float fx, float fy, double depth_scale, uint8_t* out);  /* driver/Xtion_Driver.cpp:138-162, :219-229 */
 #ifdef __cplusplus

@@ -94,6 +94,7 @@ SYMBOLS = {
     "ssvio_assemble_batch_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _vp, _vp]),
     "ssvio_track_map_points": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "ssvio_in_match_vec": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ssvio_manage_map_points": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "ssvio_rgb_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, C.c_double, _vp]),
 }
 

@@ -150,7 +150,7 @@ static int first_index_table(ssvio_matcher* m, const ssvio_dmatch* d_v, int n, i
     int rc = grow(m->d_table, m->tableCap, (size_t)std::max(tableSize, 1), s); if (rc) return rc;
     SSVIO_HIP(hipMemsetAsync(m->d_table, 0xFF, (size_t)std::max(tableSize, 1) * 4, s));
     ProfScope p(m->prof, "k_first_index", s);
-    launch_first_index(d_v, n, useTrain, m->d_table, tableSize, s);
+    launch_first_index((const int32_t*)d_v, n, 4, useTrain ? 1 : 0, m->d_table, tableSize, s);
     return SSVIO_OK;
 }
 
@@ -201,6 +201,51 @@ int ssvio_in_match_vec(ssvio_matcher* m, const ssvio_dmatch* vec, int n, int nkp
     if (n) SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, vec, (size_t)n * 16, hipMemcpyHostToDevice, s));
     rc = first_index_table(m, (const ssvio_dmatch*)m->d_frameIn, n, 0, nkp); if (rc) return rc;
     SSVIO_HIP(hipMemcpyAsync(out, m->d_table, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));    // 0xFFFFFFFF reads as -1
+    SSVIO_HIP(hipStreamSynchronize(s));
+    m->prof.resolve();
+    return SSVIO_OK;
+}
+
+int ssvio_manage_map_points(ssvio_matcher* m, const ssvio_keypoint* kps, int nkp, const uint16_t* depth, int w, int h, int stride_px,
+                            const ssvio_camera* cam, const float* world_trans, const ssvio_dmatch* last_match_vec, int nm,
+                            const int32_t* obs, int nobs, int32_t* match_num, int32_t* map_point, float* world)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    FrameCam c; int rc = cam_dev(cam, w, h, stride_px, c); if (rc) return rc;
+    if (nkp < 0 || nm < 0 || nobs < 0) { set_error("negative count"); return SSVIO_ERR_INVALID; }
+    if (nkp == 0) return SSVIO_OK;                                   // the loop of src/Map.cpp:128 does not run
+    if (!kps || !depth || !world_trans || !match_num || !map_point || !world || (nm > 0 && !last_match_vec) || (nobs > 0 && !obs)) {
+        set_error("null argument"); return SSVIO_ERR_INVALID;
+    }
+    SSVIO_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const size_t kb = align256((size_t)nkp * sizeof(ssvio_keypoint)), db = align256((size_t)h * stride_px * 2),
+                 mb = align256((size_t)std::max(nm, 1) * 16), ob = align256((size_t)std::max(nobs, 1) * 8);
+    const size_t ib = align256((size_t)nkp * 4);
+    rc = grow(m->d_frameIn, m->frameInCap, kb + db + mb + ob, s); if (rc) return rc;
+    rc = grow(m->d_frameOut, m->frameOutCap, 2 * ib + (size_t)nkp * 12, s); if (rc) return rc;
+    rc = grow(m->d_table, m->tableCap, (size_t)2 * nkp, s); if (rc) return rc;       // [0, nkp): matches by queryIdx, [nkp, 2 nkp): observations by point id
+    uint8_t* d_k = m->d_frameIn; uint8_t* d_d = d_k + kb; uint8_t* d_m = d_d + db; uint8_t* d_o = d_m + mb;
+    SSVIO_HIP(hipMemcpyAsync(d_k, kps, (size_t)nkp * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemcpyAsync(d_d, depth, (size_t)h * stride_px * 2, hipMemcpyHostToDevice, s));
+    if (nm) SSVIO_HIP(hipMemcpyAsync(d_m, last_match_vec, (size_t)nm * 16, hipMemcpyHostToDevice, s));
+    if (nobs) SSVIO_HIP(hipMemcpyAsync(d_o, obs, (size_t)nobs * 8, hipMemcpyHostToDevice, s));
+    SSVIO_HIP(hipMemsetAsync(m->d_table, 0xFF, (size_t)2 * nkp * 4, s));
+    {
+        ProfScope p(m->prof, "k_first_index", s);
+        launch_first_index((const int32_t*)d_m, nm, 4, 0, m->d_table, nkp, s);             // InMatchVec, src/Map.cpp:151-162
+        launch_first_index((const int32_t*)d_o, nobs, 2, 1, m->d_table + nkp, nkp, s);     // GetMapPointID, src/Frame.cpp:138-147
+    }
+    ManageXform T; std::memcpy(T.m, world_trans, sizeof T.m);
+    int32_t* d_mn = (int32_t*)m->d_frameOut; int32_t* d_mp = (int32_t*)(m->d_frameOut + ib); float* d_w = (float*)(m->d_frameOut + 2 * ib);
+    {
+        ProfScope p(m->prof, "k_manage", s);
+        launch_manage((const ssvio_keypoint*)d_k, nkp, (const uint16_t*)d_d, c, T, (const ssvio_dmatch*)d_m, m->d_table,
+                      (const int32_t*)d_o, m->d_table + nkp, nkp, d_mn, d_mp, d_w, s);
+    }
+    SSVIO_HIP(hipMemcpyAsync(match_num, d_mn, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipMemcpyAsync(map_point, d_mp, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));
+    SSVIO_HIP(hipMemcpyAsync(world, d_w, (size_t)nkp * 12, hipMemcpyDeviceToHost, s));
     SSVIO_HIP(hipStreamSynchronize(s));
     m->prof.resolve();
     return SSVIO_OK;

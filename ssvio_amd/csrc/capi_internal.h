@@ -4,6 +4,7 @@
 #include "match.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 

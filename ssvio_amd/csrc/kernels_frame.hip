@@ -6,6 +6,8 @@
 //   k_first_index     index map "key -> first position in a DMatch list" (atomicMin), which replaces the linear
 //                     searches of Map::InMatchVec (src/Map.cpp:151-162) and Map::TrackMapPoints (:100-123)
 //   k_track           TrackMapPoints' join through that map, emitted in last_match_vec order
+//   k_manage          Map::ManageMapPoints' per-keypoint decisions (src/Map.cpp:125-149): InMatchVec + Frame::GetMapPointID
+//                     (src/Frame.cpp:138-147) through two index maps, new points back-projected into the world frame
 //   k_rgb_cloud       the per-pixel cloud of XtionCamera::GrabImage (driver/Xtion_Driver.cpp:138-162, :219-229; f4, first half)
 // Float code is single precision, left to right, no contraction (this library is built with -ffp-contract=off).
 #include "match.h"
@@ -127,13 +129,48 @@ void launch_assemble(const AssembleArgs& a, int npairs, hipStream_t s)
     hipLaunchKernelGGL(k_assemble, dim3(npairs), dim3(256), 0, s, a);
 }
 
-// table[key] = min position j with field(v[j]) == key; table starts at 0xFFFFFFFF (= -1 as int32: "not found")
-__global__ __launch_bounds__(256) void k_first_index(const ssvio_dmatch* v, int n, int useTrain, uint32_t* table, int tableSize)
+// table[key] = min position j with rec[j].field == key; table starts at 0xFFFFFFFF (= -1 as int32: "not found").
+// Records are `strideInts` int32 wide, the key sits at int `fieldOff` (DMatch: 4 wide, queryIdx 0 / trainIdx 1;
+// observation pair {map_point_id, point_id}: 2 wide, point_id 1).
+__global__ __launch_bounds__(256) void k_first_index(const int32_t* rec, int n, int strideInts, int fieldOff, uint32_t* table, int tableSize)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const int key = useTrain ? v[j].trainIdx : v[j].queryIdx;
+    const int key = rec[(size_t)j * strideInts + fieldOff];
     if (key >= 0 && key < tableSize) atomicMin(&table[key], (uint32_t)j);
+}
+
+// Map::ManageMapPoints (src/Map.cpp:125-149), one thread per keypoint.  matchTable: first position in last_match_vec per
+// queryIdx (InMatchVec, :130); obsTable: first position in the previous key frame's observation pairs per point id
+// (Frame::GetMapPointID, src/Frame.cpp:138-147).  T: GetAbsPose().inverse() in Eigen's column-major order.
+__global__ __launch_bounds__(256) void k_manage(const ssvio_keypoint* kps, int nkp, const uint16_t* depth, FrameCam c, ManageXform T,
+                                                const ssvio_dmatch* last, const uint32_t* matchTable, const int32_t* obs,
+                                                const uint32_t* obsTable, int obsTableSize, int32_t* matchNum, int32_t* mapPoint, float* world)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nkp) return;
+    const uint32_t j = matchTable[i];
+    int mp = -1;
+    float o[3] = {0.f, 0.f, 0.f};
+    if (j == 0xFFFFFFFFu) {
+        float p[3];
+        get_3d_point(kps[i], depth, c, p);                                                // :133
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float a0 = T.m[r] * p[0], a1 = T.m[r + 4] * p[1], a2 = T.m[r + 8] * p[2];
+            const float tail = a1 + a2;
+            const float dot = a0 + tail;                                                  // Eigen's 3-term reduction: e0 + (e1 + e2)
+            o[r] = dot + T.m[r + 12];                                                     // :135-136
+        }
+    } else {
+        const int pointId = last[j].queryIdx;                                             // :143 (== i by construction of the table)
+        if (pointId >= 0 && pointId < obsTableSize) {
+            const uint32_t k = obsTable[pointId];
+            if (k != 0xFFFFFFFFu) mp = obs[2 * (size_t)k];
+        }
+    }
+    matchNum[i] = (int32_t)j; mapPoint[i] = mp;
+    world[3 * i] = o[0]; world[3 * i + 1] = o[1]; world[3 * i + 2] = o[2];
 }
 
 // Map::TrackMapPoints (src/Map.cpp:100-123): one workgroup, output in last_match_vec order
@@ -162,9 +199,17 @@ __global__ __launch_bounds__(256) void k_track(const ssvio_dmatch* last, int nla
     if (threadIdx.x == 0) *nout = written;
 }
 
-void launch_first_index(const ssvio_dmatch* v, int n, int useTrain, uint32_t* table, int tableSize, hipStream_t s)
+void launch_first_index(const int32_t* rec, int n, int strideInts, int fieldOff, uint32_t* table, int tableSize, hipStream_t s)
 {
-    if (n > 0) hipLaunchKernelGGL(k_first_index, dim3((n + 255) / 256), dim3(256), 0, s, v, n, useTrain, table, tableSize);
+    if (n > 0) hipLaunchKernelGGL(k_first_index, dim3((n + 255) / 256), dim3(256), 0, s, rec, n, strideInts, fieldOff, table, tableSize);
+}
+
+void launch_manage(const ssvio_keypoint* kps, int nkp, const uint16_t* depth, const FrameCam& c, const ManageXform& T,
+                   const ssvio_dmatch* last, const uint32_t* matchTable, const int32_t* obs, const uint32_t* obsTable, int obsTableSize,
+                   int32_t* matchNum, int32_t* mapPoint, float* world, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_manage, dim3((nkp + 255) / 256), dim3(256), 0, s, kps, nkp, depth, c, T, last, matchTable, obs, obsTable, obsTableSize,
+                       matchNum, mapPoint, world);
 }
 
 void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, const uint32_t* table, int tableSize,

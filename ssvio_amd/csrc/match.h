@@ -99,7 +99,11 @@ void launch_get_3d_points(const ssvio_keypoint* kps, int n, const uint16_t* dept
 void launch_assemble(const AssembleArgs& a, int npairs, hipStream_t s);
 void launch_rgb_cloud(const uint16_t* depth, int depthStridePx, const uint8_t* bgr, int bgrStride, int w, int h,
                       float cx, float cy, float invFx, float invFy, double depthScale, void* out, hipStream_t s);
-void launch_first_index(const ssvio_dmatch* v, int n, int useTrain, uint32_t* table, int tableSize, hipStream_t s);
+struct ManageXform { float m[16]; };                                    // Eigen::Matrix4f storage order (column-major)
+void launch_first_index(const int32_t* rec, int n, int strideInts, int fieldOff, uint32_t* table, int tableSize, hipStream_t s);
+void launch_manage(const ssvio_keypoint* kps, int nkp, const uint16_t* depth, const FrameCam& c, const ManageXform& T,
+                   const ssvio_dmatch* last, const uint32_t* matchTable, const int32_t* obs, const uint32_t* obsTable, int obsTableSize,
+                   int32_t* matchNum, int32_t* mapPoint, float* world, hipStream_t s);
 void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, const uint32_t* table, int tableSize,
                   ssvio_dmatch* out, int* nout, hipStream_t s);
 

@@ -179,6 +179,20 @@ class FeatureMatching:
         L.check(L.lib().ssvio_in_match_vec(self._h, L.ptr(v), len(v), nkp, L.ptr(out)))
         return out
 
+    def ManageMapPoints(self, kps, depth, cam, world_trans, last_match_vec, obs):
+        """the loop of Map::ManageMapPoints (src/Map.cpp:125-149) for every keypoint of the key frame:
+        (match_num, map_point, world).  world_trans: 4x4 GetAbsPose().inverse(); obs: the previous key frame's
+        (map_point_id, point_id) observation pairs (Frame::GetMapPointID, src/Frame.cpp:138-147)"""
+        kps = np.ascontiguousarray(kps, L.KP_DTYPE); depth = np.ascontiguousarray(depth, np.uint16); c = self._cam(cam)
+        T = np.ascontiguousarray(np.asarray(world_trans, np.float32).reshape(4, 4).T)       # Eigen::Matrix4f storage order
+        v = np.ascontiguousarray(last_match_vec, L.DM_DTYPE); obs = np.ascontiguousarray(obs, np.int32).reshape(-1, 2)
+        n = len(kps)
+        match_num = np.zeros(n, np.int32); map_point = np.zeros(n, np.int32); world = np.zeros((n, 3), np.float32)
+        L.check(L.lib().ssvio_manage_map_points(self._h, L.ptr(kps), n, L.ptr(depth), depth.shape[1], depth.shape[0], depth.shape[1],
+                                                L.ptr(c), L.ptr(T), L.ptr(v), len(v), L.ptr(obs), len(obs),
+                                                L.ptr(match_num), L.ptr(map_point), L.ptr(world)))
+        return match_num, map_point, world
+
     def knn2_raw(self, desp1, desp2):
         q, nq, qs = self._rows(desp1); t, nt, ts = self._rows(desp2)
         idx = np.zeros(nq, np.int32); d1 = np.zeros(nq, np.int32); d2 = np.zeros(nq, np.int32)

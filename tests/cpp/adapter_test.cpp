@@ -81,6 +81,16 @@ int main(int argc, char** argv)
             if (!ssvio::TrackMapPoints(*fd, last, c.final_good_match)) { fprintf(stderr, "track: %s\n", ssvio_last_error()); return 1; }
             std::vector<int> inm;
             if (!ssvio::InMatchVec(*fd, m, (int)kb.size(), inm)) { fprintf(stderr, "inmatch: %s\n", ssvio_last_error()); return 1; }
+            // Map::ManageMapPoints (src/Map.cpp:125-149): `last` after TrackMapPoints, the observations of the previous key frame
+            // stood in for by (1000 + j, last[j].trainIdx) pairs, world_trans = a fixed rigid motion (Eigen::Matrix4f::data() order)
+            std::vector<std::pair<int, int>> observed;
+            for (size_t j = 0; j < m.size(); j += 2) observed.push_back(std::make_pair(1000 + (int)j, m[j].queryIdx));
+            const float wt[16] = {0.f, 1.f, 0.f, 0.f,  -1.f, 0.f, 0.f, 0.f,  0.f, 0.f, 1.f, 0.f,  0.25f, -0.5f, 1.5f, 1.f};
+            std::vector<int> mnum, mpid; std::vector<ssvio::Point3f> npt;
+            if (!ssvio::ManageMapPoints(*fd, kb, depB, cam, wt, last, observed, mnum, mpid, npt)) { fprintf(stderr, "manage: %s\n", ssvio_last_error()); return 1; }
+            dump((out + ".mnum").c_str(), mnum.data(), mnum.size() * 4);
+            dump((out + ".mpid").c_str(), mpid.data(), mpid.size() * 4);
+            dump((out + ".npt").c_str(), npt.data(), npt.size() * 12);
             std::vector<unsigned> fvflat;                             // mFeatVec1_ flattened: node, count, indices...
             for (auto& e : fd->mFeatVec1_) { fvflat.push_back(e.first); fvflat.push_back((unsigned)e.second.size()); fvflat.insert(fvflat.end(), e.second.begin(), e.second.end()); }
             std::vector<double> bvflat;

@@ -64,3 +64,9 @@ def test_adapters_match_oracle(tmp_path):
     bf = O.match_bruteforce(db, da)
     assert rd(".trk") == O.track_map_points(bf, c["final_good"]).tobytes()
     assert rd(".inm") == O.in_match_vec(bf, len(kb)).tobytes()
+    trk = O.track_map_points(bf, c["final_good"])
+    obs = np.stack([1000 + np.arange(0, len(bf), 2), bf["queryIdx"][::2]], axis=1).astype(np.int32)
+    T = np.array([[0, -1, 0, 0.25], [1, 0, 0, -0.5], [0, 0, 1, 1.5], [0, 0, 0, 1]], np.float32)
+    mnum, mpid, npt = O.manage_map_points(kb, depth[1], cam, T, trk, obs)
+    assert rd(".mnum") == mnum.tobytes() and rd(".mpid") == mpid.tobytes() and rd(".npt") == npt.tobytes()
+    assert (mnum >= 0).any() and (mpid >= 0).any() and (mnum < 0).any()

@@ -274,6 +274,32 @@ def test_track_map_points_and_in_match_vec_equal_oracle(mods, seed, nlast, ncur,
     fm.close()
 
 
+@pytest.mark.parametrize("seed,nm,nobs", [(1, 400, 900), (2, 0, 50), (3, 700, 0), (4, 1500, 3000)])
+def test_manage_map_points_equals_oracle(mods, seed, nm, nobs):
+    """the loop of Map::ManageMapPoints (src/Map.cpp:125-149): InMatchVec + GetMapPointID joins and the world points of the
+    new map points, bit for bit (float order stated in include/ssvio_gpu.h)"""
+    S, synth, O, V, L = mods
+    ka, da, kb, db, depth_a, depth_b = _frame(mods, 61)
+    nkp = len(kb)
+    cam = O.camera(160.5912, 120.4792, 253.0589, 254.1649, 10.0)
+    rng = np.random.default_rng(seed)
+    v = np.zeros(nm, L.DM_DTYPE); v["queryIdx"] = rng.integers(0, nkp + 5, nm); v["trainIdx"] = rng.integers(0, nkp, nm)   # duplicates, some ids past the list
+    obs = np.stack([rng.integers(0, 5000, nobs), rng.integers(0, nkp + 5, nobs)], axis=1).astype(np.int32)
+    a = rng.normal(size=3); a /= np.linalg.norm(a); th = 0.7
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    T = np.eye(4); T[:3, :3] = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K; T[:3, 3] = rng.normal(size=3) * 2
+    fm = S.FeatureMatching(None, {})
+    got = fm.ManageMapPoints(kb, depth_b, cam, T, v, obs)
+    want = O.manage_map_points(kb, depth_b, cam, T, v, obs)
+    for g, w_ in zip(got, want):
+        assert g.shape == w_.shape and np.array_equal(_bytes(g), _bytes(w_))
+    assert np.array_equal(got[0], O.in_match_vec(v, nkp))
+    if nm and nobs:
+        assert (got[1] >= 0).sum() > 10 and ((got[0] >= 0) & (got[1] < 0)).any() and (got[0] < 0).any()
+    assert all(len(x) == 0 for x in fm.ManageMapPoints(kb[:0], depth_b, cam, T, v, obs))
+    fm.close()
+
+
 @pytest.mark.parametrize("h,w", [(240, 320), (480, 640), (37, 53), (1, 1)])
 def test_rgb_cloud_equals_oracle(mods, h, w):
     S, synth, O, V, L = mods

@@ -214,6 +214,30 @@ def test_in_match_vec_first_position(oracle):
     assert oracle.in_match_vec(v[:0], 3).tolist() == [-1, -1, -1]
 
 
+def test_manage_map_points_decisions_and_world_points(oracle):
+    # src/Map.cpp:125-149.  5 keypoints; last_match_vec query ids [3, 1, 3]: keypoints 1 and 3 are tracked (3 -> first position 0)
+    cam = oracle.camera(0.0, 0.0, 1.0, 1.0, 65535.0)                     # depth value = raw, x = px * d, y = py * d
+    depth = np.array([[2, 4, 6, 8, 10]], np.uint16)
+    kps = _kps(oracle, [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0)])
+    v = np.zeros(3, oracle.DM_DTYPE); v["queryIdx"] = [3, 1, 3]; v["trainIdx"] = [30, 10, 31]
+    # previous key frame's observations {map_point_id, point_id}: point 3 seen as map point 77 first, then 78; point 1 never
+    obs = [(70, 0), (77, 3), (78, 3), (79, 9)]
+    T = np.array([[0, -1, 0, 10], [1, 0, 0, 20], [0, 0, 1, 30], [0, 0, 0, 1]], np.float32)     # rotate 90 deg about z, then translate
+    match_num, map_point, world = oracle.manage_map_points(kps, depth, cam, T, v, obs)
+    assert match_num.tolist() == [-1, 1, -1, 0, -1]
+    assert map_point.tolist() == [-1, -1, -1, 77, -1]                     # keypoint 1: no observation (undefined in the reference) -> -1
+    # keypoint 2: p = (2 * 6, 0, 6) -> (-0 + 10, 12 + 20, 6 + 30);  keypoint 4: p = (40, 0, 10) -> (10, 60, 40);  tracked rows stay 0
+    assert world.tolist() == [[10.0, 20.0, 32.0], [0.0, 0.0, 0.0], [10.0, 32.0, 36.0], [0.0, 0.0, 0.0], [10.0, 60.0, 40.0]]
+    # float order e0 + (e1 + e2), then + t: with e0 = 2^24, e1 = e2 = 1 the pair sum 2 survives, one at a time it would not
+    T2 = np.eye(4, dtype=np.float32); T2[0, :3] = [2.0 ** 24, 1.0, 1.0]
+    cam2 = oracle.camera(0.0, 0.0, 1.0, 1.0, 65535.0)
+    k2 = _kps(oracle, [(1, 1)])                                           # p = (1 * 1, 1 * 1, 1) with depth 1
+    _, _, w2 = oracle.manage_map_points(k2, np.array([[0, 0], [0, 1]], np.uint16), cam2, T2, v[:0], [])
+    assert w2[0, 0] == np.float32(2.0 ** 24 + 2.0)
+    n0 = oracle.manage_map_points(kps[:0], depth, cam, T, v, obs)
+    assert all(len(a) == 0 for a in n0)
+
+
 def test_rgb_cloud_known_values(oracle):
     depth = np.array([[0, 65535], [13107, 100]], np.uint16)             # (y, x)
     bgr = np.arange(12, dtype=np.uint8).reshape(2, 2, 3)
