@@ -55,6 +55,10 @@ def test_gpu_outputs_equal_the_committed_digests():
     c = fm.AssembleCorrespondences(md, ka, depth_a, kb, depth_b, cam)
     assert {k: dg(v) for k, v in sorted(c.items())} == want["assemble"]
     assert dg(fm.TrackMapPoints(m, c["final_good"])) == want["track_map_points"]
+    trk = fm.TrackMapPoints(m, c["final_good"])
+    obs = np.stack([1000 + np.arange(0, len(m), 2), m["queryIdx"][::2]], axis=1).astype(np.int32)
+    T = np.array([[0, -1, 0, 0.25], [1, 0, 0, -0.5], [0, 0, 1, 1.5], [0, 0, 0, 1]], np.float32)
+    assert dg(*fm.ManageMapPoints(kb, depth_b, cam, T, trk, obs)) == want["manage_map_points"]
     assert dg(fm.RGBCloud(depth_a, rgb, cam, 10.0)) == want["rgb_cloud"]
     p3 = np.stack([(ka["x"] - 160.0) / 260.0 * 2.0, (ka["y"] - 120.0) / 260.0 * 2.0, np.full(len(ka), 2.0)], 1).astype(np.float64)
     p2 = np.stack([kb["x"], kb["y"]], 1).astype(np.float64)

@@ -53,6 +53,10 @@ def compute():
     c = O.assemble_correspondences(md, ka, depth_a, kb, depth_b, cam)
     out["assemble"] = {k: dg(v) for k, v in sorted(c.items())}
     out["track_map_points"] = dg(O.track_map_points(m, c["final_good"]))
+    trk = O.track_map_points(m, c["final_good"])
+    obs = np.stack([1000 + np.arange(0, len(m), 2), m["queryIdx"][::2]], axis=1).astype(np.int32)
+    T = np.array([[0, -1, 0, 0.25], [1, 0, 0, -0.5], [0, 0, 1, 1.5], [0, 0, 0, 1]], np.float32)
+    out["manage_map_points"] = dg(*O.manage_map_points(kb, depth_b, cam, T, trk, obs))
     out["rgb_cloud"] = dg(O.rgb_cloud(depth_a, rgb, 160.5912, 120.4792, 253.0589, 254.1649, 10.0))
     p3 = np.stack([(ka["x"] - 160.0) / 260.0 * 2.0, (ka["y"] - 120.0) / 260.0 * 2.0, np.full(len(ka), 2.0)], 1).astype(np.float64)
     p2 = np.stack([kb["x"], kb["y"]], 1).astype(np.float64)
