@@ -410,6 +410,7 @@ static int orb_enqueue(ssvio_orb* h, int batch)
         launch_describe(h->d_pyr, h->d_blur, g.frameBytes, h->kl, h->d_sel, h->d_selCount, h->kpCap, h->kpCap, h->d_kpOut, h->d_desc,
                         h->d_kpCount, h->d_kpCountHost, batch, s);
     }
+    SSVIO_HIP(hipGetLastError());                                 // a refused launch configuration shows up only here
     return SSVIO_OK;
 }
 
@@ -571,6 +572,7 @@ static int orb_extract_dev(ssvio_orb* h, const void* d_imgs, int batch, int chan
                                   h->d_rawCount, batch * kMaxLevels, h->d_cellIni, batch * g.cellsPerFrame, h->stream);
         else launch_copy_gray((const uint8_t*)d_imgs, width, height, stride, frame_stride, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
                                   h->d_rawCount, batch * kMaxLevels, h->d_cellIni, batch * g.cellsPerFrame, h->stream);
+        SSVIO_HIP(hipGetLastError());
     }
     rc = orb_run(h, batch, wait);
     if (rc) return rc;
@@ -671,6 +673,7 @@ int ssvio_orb_extract_batch(ssvio_orb* h, const uint8_t* imgs, int batch, int ch
                                   h->d_rawCount, batch * kMaxLevels, h->d_cellIni, batch * g.cellsPerFrame, h->stream);
         else launch_copy_gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
                                   h->d_rawCount, batch * kMaxLevels, h->d_cellIni, batch * g.cellsPerFrame, h->stream);
+        SSVIO_HIP(hipGetLastError());
     }
     rc = orb_run(h, batch);
     if (rc) return rc;

@@ -133,6 +133,7 @@ int ssvio_bow_transform(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* d
     SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
     SSVIO_HIP(hipStreamSynchronize(s));
     bow_run(m, v, m->d_q, 0, m->d_counts2, 1, n, levelsup, 0);
+    SSVIO_HIP(hipGetLastError());
     if (word) SSVIO_HIP(hipMemcpyAsync(word, m->d_bowWord, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     if (node) SSVIO_HIP(hipMemcpyAsync(node, m->d_bowNode, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     if (weight) SSVIO_HIP(hipMemcpyAsync(weight, m->d_bowWeight, (size_t)n * 8, hipMemcpyDeviceToHost, s));
@@ -181,6 +182,7 @@ int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, i
         g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
         ProfScope p(m->prof, "k_match_sorted", s);
         launch_match_sorted(g, nq, nt, 1, s);
+        SSVIO_HIP(hipGetLastError());
     } else {                                                           // sets beyond the LDS sort: wave per query over all train rows
         GroupedArgs g{};
         g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + nq;
@@ -189,6 +191,7 @@ int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, i
         g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
         ProfScope p(m->prof, "k_match_grouped", s);
         launch_match_grouped(g, nq, 1, s);
+        SSVIO_HIP(hipGetLastError());
     }
     int cnt = 0;
     SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -245,6 +248,7 @@ int ssvio_match_dbow_batch_dev(ssvio_matcher* m, const ssvio_vocab* v, const voi
         g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
         ProfScope p(m->prof, "k_match_sorted", s);
         launch_match_sorted(g, max_rows, max_rows, npairs, s);
+        SSVIO_HIP(hipGetLastError());
     } else {
         GroupedArgs g{};
         g.qdesc = (const uint4*)d_desc; g.tdesc = (const uint4*)d_desc; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode;
@@ -253,6 +257,7 @@ int ssvio_match_dbow_batch_dev(ssvio_matcher* m, const ssvio_vocab* v, const voi
         g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
         ProfScope p(m->prof, "k_match_grouped", s);
         launch_match_grouped(g, max_rows, npairs, s);
+        SSVIO_HIP(hipGetLastError());
     }
     m->lastPairs = npairs; m->lastMaxRows = max_rows;
     m->lastBowQ = 0; m->lastBowT = 0;

@@ -46,6 +46,7 @@ int ssvio_get_3d_points(ssvio_matcher* m, const ssvio_keypoint* kps, int n, cons
     {
         ProfScope p(m->prof, "k_get_3d_points", s);
         launch_get_3d_points((const ssvio_keypoint*)m->d_frameIn, n, (const uint16_t*)(m->d_frameIn + kb), c, (float*)m->d_frameOut, s);
+        SSVIO_HIP(hipGetLastError());
     }
     SSVIO_HIP(hipMemcpyAsync(out, m->d_frameOut, (size_t)n * 12, hipMemcpyDeviceToHost, s));
     SSVIO_HIP(hipStreamSynchronize(s));
@@ -96,6 +97,7 @@ int ssvio_assemble_correspondences(ssvio_matcher* m, const ssvio_dmatch* matches
     {
         ProfScope p(m->prof, "k_assemble", s);
         launch_assemble(a, 1, s);
+        SSVIO_HIP(hipGetLastError());
     }
     int got[2] = {0, 0};
     SSVIO_HIP(hipMemcpyAsync(got, a.counts, sizeof got, hipMemcpyDeviceToHost, s));
@@ -137,6 +139,7 @@ int ssvio_assemble_batch_dev(ssvio_matcher* m, const void* d_matches, const int3
     {
         ProfScope p(m->prof, "k_assemble", m->stream);
         launch_assemble(a, npairs, m->stream);
+        SSVIO_HIP(hipGetLastError());
     }
     out->last3d = a.last3d; out->cur2d = a.cur2d; out->cur3d = a.cur3d; out->pre_good = a.preGood;
     out->edge_last3d = a.edgeLast3d; out->edge_cur3d = a.edgeCur3d; out->final_good = a.finalGood; out->counts = a.counts;
@@ -151,6 +154,7 @@ static int first_index_table(ssvio_matcher* m, const ssvio_dmatch* d_v, int n, i
     SSVIO_HIP(hipMemsetAsync(m->d_table, 0xFF, (size_t)std::max(tableSize, 1) * 4, s));
     ProfScope p(m->prof, "k_first_index", s);
     launch_first_index((const int32_t*)d_v, n, 4, useTrain ? 1 : 0, m->d_table, tableSize, s);
+    SSVIO_HIP(hipGetLastError());
     return SSVIO_OK;
 }
 
@@ -179,6 +183,7 @@ int ssvio_track_map_points(ssvio_matcher* m, const ssvio_dmatch* last, int nlast
     {
         ProfScope p(m->prof, "k_track", s);
         launch_track((const ssvio_dmatch*)m->d_frameIn, nlast, (const ssvio_dmatch*)(m->d_frameIn + lb), m->d_table, maxKey + 1, m->d_out, m->d_nout, s);
+        SSVIO_HIP(hipGetLastError());
     }
     int cnt = 0;
     SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -237,11 +242,13 @@ int ssvio_manage_map_points(ssvio_matcher* m, const ssvio_keypoint* kps, int nkp
         launch_first_index((const int32_t*)d_o, nobs, 2, 1, m->d_table + nkp, nkp, s);     // GetMapPointID, src/Frame.cpp:138-147
     }
     ManageXform T; std::memcpy(T.m, world_trans, sizeof T.m);
+        SSVIO_HIP(hipGetLastError());
     int32_t* d_mn = (int32_t*)m->d_frameOut; int32_t* d_mp = (int32_t*)(m->d_frameOut + ib); float* d_w = (float*)(m->d_frameOut + 2 * ib);
     {
         ProfScope p(m->prof, "k_manage", s);
         launch_manage((const ssvio_keypoint*)d_k, nkp, (const uint16_t*)d_d, c, T, (const ssvio_dmatch*)d_m, m->d_table,
                       (const int32_t*)d_o, m->d_table + nkp, nkp, d_mn, d_mp, d_w, s);
+        SSVIO_HIP(hipGetLastError());
     }
     SSVIO_HIP(hipMemcpyAsync(match_num, d_mn, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));
     SSVIO_HIP(hipMemcpyAsync(map_point, d_mp, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));
@@ -271,6 +278,7 @@ extern "C" int ssvio_rgb_cloud(ssvio_matcher* m, const uint16_t* depth, int dept
         ProfScope p(m->prof, "k_rgb_cloud", s);
         launch_rgb_cloud((const uint16_t*)m->d_frameIn, depth_stride_px, m->d_frameIn + db, bgr_stride, w, h, c.cx, c.cy, c.invFx, c.invFy,
                          depth_scale, m->d_frameOut, s);
+        SSVIO_HIP(hipGetLastError());
     }
     SSVIO_HIP(hipMemcpyAsync(out, m->d_frameOut, ob, hipMemcpyDeviceToHost, s));
     SSVIO_HIP(hipStreamSynchronize(s));

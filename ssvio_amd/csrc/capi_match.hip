@@ -62,6 +62,7 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
     {
         ProfScope p(m->prof, "k_hamming_knn2", s);
         launch_knn2(a, maxQ, npairs, s);
+        SSVIO_HIP(hipGetLastError());
     }
     FinalizeArgs f{};
     f.partial = m->d_partial; f.nChunks = nChunks; f.maxRows = maxRows;
@@ -80,12 +81,14 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
         {
             ProfScope p(m->prof, "k_hamming_knn2", s);
             launch_knn2(r, maxT, npairs, s);
+            SSVIO_HIP(hipGetLastError());
         }
         f.partialRev = m->d_partialRev; f.nChunksRev = nChunksR;
     }
     {
         ProfScope p(m->prof, "k_match_finalize", s);
         launch_finalize(f, npairs, maxQ, maxT, s);
+        SSVIO_HIP(hipGetLastError());
     }
     m->lastPairs = npairs; m->lastMaxRows = maxRows;
     return SSVIO_OK;
@@ -256,6 +259,7 @@ int ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, i
     {
         ProfScope p(m->prof, "k_match_project", s);
         launch_project(a, s);
+        SSVIO_HIP(hipGetLastError());
     }
     int cnt = 0;
     SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));

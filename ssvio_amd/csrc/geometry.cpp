@@ -20,6 +20,7 @@ const char* last_error_cstr() { return g_err.c_str(); }
 int hip_fail(hipError_t e, const char* what, const char* file, int line)
 {
     set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    (void)hipGetLastError();                  // reported once: the launch checks read the runtime's last-error slot
     return SSVIO_ERR_HIP;
 }
 
