@@ -163,6 +163,23 @@ def test_low_texture_min_threshold_fallback(mods):
     g.close()
 
 
+def test_nms_tie_then_min_threshold_retry_known_answer(mods):
+    """hand-derived case (tests/test_oracle_kat.py): two adjacent equal-score corners suppress each other, the cell is empty
+    at iniTh, the retry at minTh finds the weak corner; with one strong corner there is no retry"""
+    S, synth, O = mods
+    def spikes(pair):
+        img = np.full((100, 100), 100, np.uint8); img[30, 30] = 200; img[40, 40] = 110
+        if pair: img[30, 31] = 200
+        return img
+    g = S.ORBextractor(500, 1.2, 1, 20, 7); c = O.Extractor(500, 1.2, 1, 20, 7)
+    for pair, want in ((True, (40.0, 40.0, 9.0)), (False, (30.0, 30.0, 99.0))):
+        kps, desc = g.Extract(spikes(pair))
+        assert [(float(k["x"]), float(k["y"]), float(k["response"])) for k in kps] == [want]
+        rk, rd = c.extract(spikes(pair))
+        assert np.array_equal(kps.view(np.uint8), rk.view(np.uint8)) and np.array_equal(desc, rd)
+    g.close()
+
+
 def test_flat_and_empty_inputs(mods):
     S, synth, O = mods
     g = S.ORBextractor(1000, 1.2, 8, 20, 7)

@@ -142,6 +142,26 @@ def test_fast_oracle_equals_independent_numpy_definition(oracle, seed, T):
     assert len(ref) > 0
 
 
+def _spikes(pair):
+    img = np.full((100, 100), 100, np.uint8)
+    img[30, 30] = 200                                # an isolated bright pixel: all 16 ring pixels darker by 100 -> score 99
+    if pair:
+        img[30, 31] = 200                            # its twin one pixel to the right: same score (neither lies on the other's ring)
+    img[40, 40] = 110                                # a weak spike in the same 34-px cell: score 9, a corner at minTh 7 only
+    return img
+
+
+def test_nms_tie_empties_the_cell_and_the_min_threshold_retry_fires(oracle):
+    """src/Feature.cpp:872-879: equal adjacent scores suppress each other (strict >), cv::FAST at iniTh returns nothing for
+    the cell, so the cell is searched again at minTh -- and only then the weak corner appears"""
+    assert len(oracle.fast9(_spikes(True), 20)[0]) == 0 and list(oracle.fast9(_spikes(False), 20)[2]) == [99]
+    ex = oracle.Extractor(500, 1.2, 1, 20, 7)
+    k, _ = ex.extract(_spikes(True))
+    assert [(float(a), float(b), float(c)) for a, b, c in zip(k["x"], k["y"], k["response"])] == [(40.0, 40.0, 9.0)]
+    k, _ = ex.extract(_spikes(False))                # one strong corner: the first search is not empty, no retry, no weak corner
+    assert [(float(a), float(b), float(c)) for a, b, c in zip(k["x"], k["y"], k["response"])] == [(30.0, 30.0, 99.0)]
+
+
 def test_fast_score_is_threshold_independent_for_corners(oracle):
     """the property the GPU kernel relies on: corner@T <=> score(T=0 definition) >= T"""
     from ssvio_amd import synth
