@@ -1,9 +1,11 @@
 // FeatureMatching.h -- drop-in for SSVIO's include/FeatureMatching.h:13-54 on the gfx950 library.
 // The constructor keeps its shape (vocabulary path + config); the config is anything with
 // GetParam<T>(key) like SSVIO's Config (include/Config.h:26-30).  The vocabulary (DBoW3::Vocabulary in the
-// reference, src/FeatureMatching.cpp:8-9) is read from voc_dataset when that is a text vocabulary
-// (DBoW3 load_fromtxt / ORBvoc.txt layout: "k L scoring weighting", then "parent is_leaf d0..d31 weight" per
-// node) or handed over as arrays with SetVocabulary; DBoW3's compressed binary container is not read.  Without
+// reference, src/FeatureMatching.cpp:8-9) is read from voc_dataset the way DBoW3's Vocabulary::load tries it:
+// the uncompressed binary stream when the file starts with DBoW3's signature (toStream / fromStream layout, restated
+// from DBoW3's published source -- no .dbow3 file exists here to check it against), else the text layout (DBoW3
+// load_fromtxt / ORBvoc.txt: "k L scoring weighting", then "parent is_leaf d0..d31 weight" per node); or it is handed
+// over as arrays with SetVocabulary.  The QuickLZ-compressed stream and the YAML container are not read.  Without
 // a vocabulary MatchByDBoW returns false (lastStatus() tells why).
 #pragma once
 #include <cmath>
@@ -28,7 +30,7 @@ public:
         mTh_ = config->template GetParam<int>("Threshold");          // src/FeatureMatching.cpp:10
         mNNRatio_ = config->template GetParam<float>("NNRatio");      // :11
         init(device);
-        LoadVocabularyTxt(voc_.c_str());                              // :8-9 (a missing / unreadable file leaves no vocabulary)
+        LoadVocabulary(voc_.c_str());                                 // :8-9 (a missing / unreadable file leaves no vocabulary)
     }
     FeatureMatching(int threshold, float nnRatio, int device = 0) : mTh_(threshold), mNNRatio_(nnRatio) { init(device); }
     ~FeatureMatching() { ssvio_matcher_destroy(m_); ssvio_vocab_destroy(v_); }
@@ -78,6 +80,49 @@ public:
             parent.push_back(pid); weight.push_back(w); word.push_back(leaf > 0 ? nwords++ : -1);
         }
         return SetVocabulary(k, L, parent, desc, weight, word, scoring, weighting);
+    }
+    // DBoW3's uncompressed binary stream: u64 88877711233 | u8 compressed | u32 nnodes | i32 k, L, scoring, weighting |
+    // nnodes-1 x {u32 id, u32 parent, f64 weight, 3 x i32 {cols, rows, type}, 32 bytes} | u32 nwords | nwords x {u32 word, u32 node}
+    bool LoadVocabularyBinary(const char* path)
+    {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) return false;
+        uint64_t sig = 0; uint8_t compressed = 1; uint32_t n = 0; int32_t hd[4] = {0, 0, 0, 0};
+        f.read((char*)&sig, 8); f.read((char*)&compressed, 1); f.read((char*)&n, 4); f.read((char*)hd, 16);
+        if (!f || sig != 88877711233ull || compressed != 0 || n < 1 || n > (1u << 28)) return false;
+        std::vector<int32_t> parent(n, -2), word(n, -1); std::vector<uint8_t> desc((size_t)n * 32, 0); std::vector<double> weight(n, 0.0);
+        std::vector<uint32_t> lastChild(n, 0); std::vector<uint8_t> inner(n, 0);
+        parent[0] = -1;
+        for (uint32_t i = 1; i < n; ++i) {
+            uint32_t id = 0, pid = 0; double w = 0; int32_t h3[3] = {0, 0, 0};
+            f.read((char*)&id, 4); f.read((char*)&pid, 4); f.read((char*)&w, 8); f.read((char*)h3, 12);
+            if (!f || id < 1 || id >= n || pid >= id || parent[id] != -2) return false;        // a tree numbered parent-first, every id once
+            if (h3[0] < 0 || h3[1] < 0 || h3[2] < 0 || h3[0] + h3[1] + h3[2] != 33 || h3[0] * h3[1] + h3[1] * h3[2] + h3[0] * h3[2] != 32) return false;   // {32 cols, 1 row, CV_8U = 0}, any order
+            if (id <= lastChild[pid]) return false;                    // children are tried in file order: must be ascending id
+            lastChild[pid] = id; inner[pid] = 1;
+            parent[id] = (int32_t)pid; weight[id] = w;
+            f.read((char*)&desc[(size_t)id * 32], 32);
+            if (!f) return false;
+        }
+        uint32_t nw = 0; f.read((char*)&nw, 4);
+        if (!f || nw > n) return false;
+        uint32_t leaves = 0;
+        for (uint32_t i = (n > 1 ? 1 : 0); i < n; ++i) leaves += inner[i] ? 0 : 1;
+        if (nw != leaves) return false;
+        std::vector<uint8_t> used(nw, 0);
+        for (uint32_t i = 0; i < nw; ++i) {
+            uint32_t wid = 0, nid = 0; f.read((char*)&wid, 4); f.read((char*)&nid, 4);
+            if (!f || wid >= nw || nid >= n || inner[nid] || used[wid] || word[nid] != -1) return false;
+            used[wid] = 1; word[nid] = (int32_t)wid;
+        }
+        return SetVocabulary(hd[0], hd[1], parent, desc, weight, word, hd[2], hd[3]);
+    }
+    // DBoW3 Vocabulary::load: the binary stream first, else the text layout
+    bool LoadVocabulary(const char* path)
+    {
+        uint64_t sig = 0;
+        { std::ifstream f(path, std::ios::binary); if (!f) return false; f.read((char*)&sig, 8); if (!f) sig = 0; }
+        return sig == 88877711233ull ? LoadVocabularyBinary(path) : LoadVocabularyTxt(path);
     }
     bool HasVocabulary() const { return v_ != nullptr; }
 

@@ -103,6 +103,19 @@ int main(int argc, char** argv)
             dump((out + ".fin").c_str(), c.final_good_match.data(), c.final_good_match.size() * sizeof(cv::DMatch));
             dump((out + ".trk").c_str(), last.data(), last.size() * sizeof(cv::DMatch));
             dump((out + ".inm").c_str(), inm.data(), inm.size() * 4);
+            if (argc >= 9) {
+                // the same vocabulary as DBoW3's uncompressed binary stream (what Vocabulary::load tries first): same matches
+                FeatureMatching::Ptr fb = std::make_shared<FeatureMatching>(argv[8], cfg);
+                std::vector<cv::DMatch> bow2;
+                if (!fb->HasVocabulary()) { fprintf(stderr, "binary vocabulary not loaded\n"); return 1; }
+                fb->MatchByDBoW(db, da, bow2);
+                if (bow2.size() != bow.size() || (bow.size() && memcmp(bow2.data(), bow.data(), bow.size() * sizeof(cv::DMatch)) != 0)) {
+                    fprintf(stderr, "binary and text vocabulary disagree\n"); return 1;
+                }
+                FeatureMatching::Ptr fbad = std::make_shared<FeatureMatching>(argv[1], cfg);      // the raw frames: not a vocabulary at all
+                if (fbad->HasVocabulary()) { fprintf(stderr, "garbage accepted as a vocabulary\n"); return 1; }
+                printf("binary_voc=same\n");
+            }
             printf("bow=%zu pre=%zu final=%zu track=%zu\n", bow.size(), c.pre_good_match.size(), c.final_good_match.size(), last.size());
         }
         dump((out + ".p3").c_str(), p3.data(), p3.size() * sizeof(cv::Point3d));

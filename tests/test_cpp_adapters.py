@@ -29,9 +29,11 @@ def test_adapters_match_oracle(tmp_path):
     voc.save_txt(str(tmp_path / "voc.txt"))
     depth = np.stack([synth.depth_image(5, 240, 320), synth.depth_image(6, 240, 320)])
     (tmp_path / "depth.raw").write_bytes(depth.tobytes())
-    r = subprocess.run([EXE, str(raw), "320", "240", "1200", out, str(tmp_path / "voc.txt"), str(tmp_path / "depth.raw")],
+    voc.save_dbow3(str(tmp_path / "voc.dbow3"))
+    r = subprocess.run([EXE, str(raw), "320", "240", "1200", out, str(tmp_path / "voc.txt"), str(tmp_path / "depth.raw"), str(tmp_path / "voc.dbow3")],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
+    assert "binary_voc=same" in r.stdout
     assert "pyr0=320x240" in r.stdout
     ex = O.Extractor(1200, 1.2, 8, 20, 7)
     ka, da = ex.extract(a); kb, db = ex.extract(b)

@@ -161,6 +161,46 @@ def test_host_vocabulary_maps_and_text_format(oracle, tmp_path):
     assert np.array_equal(r.weight[1:], v.weight[1:]) and np.array_equal(r.word, v.word)
 
 
+def test_dbow3_binary_stream_round_trip_and_refusals(tmp_path):
+    """DBoW3's uncompressed toStream / fromStream layout as ssvio_amd.vocabulary restates it (no .dbow3 file exists here to
+    pin it: this checks the reader against the writer, the header-order tolerance and what is refused)"""
+    import struct
+    from ssvio_amd import synth
+    from ssvio_amd.vocabulary import Vocabulary
+    par, desc, w = synth.vocabulary_tables(11, 4, 3, early_leaf_p=0.25)
+    v = Vocabulary(4, 3, par, desc, w, scoring=1, weighting=2)
+    p = str(tmp_path / "v.dbow3")
+    v.save_dbow3(p)
+    raw = open(p, "rb").read()
+    assert struct.unpack_from("<QBI4i", raw, 0) == (88877711233, 0, len(par), 4, 3, 1, 2)
+    assert Vocabulary.is_dbow3(p)
+    r = Vocabulary.load(p)
+    assert (r.k, r.L, r.scoring, r.weighting) == (4, 3, 1, 2)
+    assert np.array_equal(r.parent, v.parent) and np.array_equal(r.desc[1:], v.desc[1:]) and np.array_equal(r.weight[1:], v.weight[1:])
+    assert np.array_equal(r.word, v.word)
+    # records are not in id order in the stream (stack walk): the first record's parent is the root, a later one jumps back
+    ids = [struct.unpack_from("<I", raw, 29 + 60 * i)[0] for i in range(len(par) - 1)]
+    assert ids != sorted(ids) and sorted(ids) == list(range(1, len(par)))
+    # descriptor header written as (type, cols, rows) instead of (cols, rows, type): still understood
+    alt = bytearray(raw)
+    for i in range(len(par) - 1):
+        struct.pack_into("<3i", alt, 29 + 60 * i + 16, 0, 32, 1)
+    open(p, "wb").write(bytes(alt))
+    assert np.array_equal(Vocabulary.load(p).desc, r.desc)
+    # refused: compressed flag, truncated file, a word that names an inner node, a 64-byte descriptor header
+    def refused(b):
+        open(p, "wb").write(bytes(b))
+        with pytest.raises(ValueError):
+            Vocabulary.load_dbow3(p)
+    b = bytearray(raw); b[8] = 1; refused(b)
+    refused(raw[:len(raw) // 2])
+    b = bytearray(raw); struct.pack_into("<I", b, len(raw) - 4, 0); refused(b)            # last word -> node 0 (the root)
+    b = bytearray(raw); struct.pack_into("<i", b, 29 + 16, 64); refused(b)
+    # a text vocabulary goes to the text reader
+    t = str(tmp_path / "v.txt"); v.save_txt(t)
+    assert not Vocabulary.is_dbow3(t) and np.array_equal(Vocabulary.load(t).parent, v.parent)
+
+
 # ---------------------------------------------------------------- behind the matcher
 def _kps(oracle, pts):
     k = np.zeros(len(pts), oracle.KP_DTYPE)
