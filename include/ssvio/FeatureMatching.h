@@ -89,7 +89,11 @@ public:
         if (!f) return false;
         uint64_t sig = 0; uint8_t compressed = 1; uint32_t n = 0; int32_t hd[4] = {0, 0, 0, 0};
         f.read((char*)&sig, 8); f.read((char*)&compressed, 1); f.read((char*)&n, 4); f.read((char*)hd, 16);
-        if (!f || sig != 88877711233ull || compressed != 0 || n < 1 || n > (1u << 28)) return false;
+        if (!f || sig != 88877711233ull || compressed != 0 || n < 1) return false;
+        f.seekg(0, std::ios::end);
+        const uint64_t fileBytes = (uint64_t)f.tellg();
+        if (fileBytes < 29 + (uint64_t)(n - 1) * 60 + 4) return false;  // the node records must fit the file before anything is sized by n
+        f.seekg(29, std::ios::beg);
         std::vector<int32_t> parent(n, -2), word(n, -1); std::vector<uint8_t> desc((size_t)n * 32, 0); std::vector<double> weight(n, 0.0);
         std::vector<uint32_t> lastChild(n, 0); std::vector<uint8_t> inner(n, 0);
         parent[0] = -1;

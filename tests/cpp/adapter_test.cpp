@@ -114,6 +114,10 @@ int main(int argc, char** argv)
                 }
                 FeatureMatching::Ptr fbad = std::make_shared<FeatureMatching>(argv[1], cfg);      // the raw frames: not a vocabulary at all
                 if (fbad->HasVocabulary()) { fprintf(stderr, "garbage accepted as a vocabulary\n"); return 1; }
+                for (int a = 9; a < argc; ++a) {                      // corrupt binary streams: refused, never guessed at
+                    FeatureMatching::Ptr fc = std::make_shared<FeatureMatching>(argv[a], cfg);
+                    if (fc->HasVocabulary()) { fprintf(stderr, "corrupt vocabulary %s accepted\n", argv[a]); return 1; }
+                }
                 printf("binary_voc=same\n");
             }
             printf("bow=%zu pre=%zu final=%zu track=%zu\n", bow.size(), c.pre_good_match.size(), c.final_good_match.size(), last.size());

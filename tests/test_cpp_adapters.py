@@ -30,7 +30,15 @@ def test_adapters_match_oracle(tmp_path):
     depth = np.stack([synth.depth_image(5, 240, 320), synth.depth_image(6, 240, 320)])
     (tmp_path / "depth.raw").write_bytes(depth.tobytes())
     voc.save_dbow3(str(tmp_path / "voc.dbow3"))
-    r = subprocess.run([EXE, str(raw), "320", "240", "1200", out, str(tmp_path / "voc.txt"), str(tmp_path / "depth.raw"), str(tmp_path / "voc.dbow3")],
+    import struct
+    good = (tmp_path / "voc.dbow3").read_bytes()
+    bad = []
+    for i, blob in enumerate([good[:len(good) // 3],                                              # truncated
+                           good[:9] + struct.pack("<I", 1 << 30) + good[13:],                  # node count far beyond the file
+                           good[:8] + b"\x01" + good[9:],                                      # compressed flag
+                           good[:29 + 4] + struct.pack("<I", 7) + good[29 + 8:]]):             # first node's parent is not before it
+        (tmp_path / ("bad%d.dbow3" % i)).write_bytes(blob); bad.append(str(tmp_path / ("bad%d.dbow3" % i)))
+    r = subprocess.run([EXE, str(raw), "320", "240", "1200", out, str(tmp_path / "voc.txt"), str(tmp_path / "depth.raw"), str(tmp_path / "voc.dbow3")] + bad,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "binary_voc=same" in r.stdout
