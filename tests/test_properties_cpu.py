@@ -87,3 +87,34 @@ def test_host_bow_vector_equals_oracle(oracle, seed, k, L, n, scoring, weighting
         while par[chain[-1]] >= 0:
             chain.append(int(par[chain[-1]]))
         assert int(node[f]) in chain
+
+
+@settings(**CFG)
+@given(seed=st.integers(0, 2**31 - 1), nkp=st.integers(0, 60), nm=st.integers(0, 80), nobs=st.integers(0, 80))
+def test_manage_map_points_against_a_literal_restatement(oracle, seed, nkp, nm, nobs):
+    """src/Map.cpp:125-149 + src/Frame.cpp:138-147 with python lists and numpy float32 scalars, one operation at a time"""
+    rng = np.random.default_rng(seed)
+    f = np.float32
+    kps = np.zeros(nkp, oracle.KP_DTYPE); kps["x"] = rng.random(nkp) * 39; kps["y"] = rng.random(nkp) * 29
+    depth = rng.integers(0, 65536, (30, 40)).astype(np.uint16)
+    cam = oracle.camera(19.5, 14.25, 31.0, 32.5, 10.0)
+    T = rng.normal(size=(4, 4)).astype(np.float32); T[3] = [0, 0, 0, 1]
+    v = np.zeros(nm, oracle.DM_DTYPE); v["queryIdx"] = rng.integers(0, nkp + 3, nm); v["trainIdx"] = rng.integers(0, 99, nm)
+    obs = np.stack([rng.integers(0, 999, nobs), rng.integers(0, nkp + 3, nobs)], axis=1).astype(np.int32)
+    match_num, map_point, world = oracle.manage_map_points(kps, depth, cam, T, v, obs)
+    inv_fx, inv_fy = f(1) / cam[2], f(1) / cam[3]
+    for i in range(nkp):
+        hit = [j for j in range(nm) if v["queryIdx"][j] == i]
+        if hit:
+            assert match_num[i] == hit[0] and (world[i] == 0).all()
+            pid = v["queryIdx"][hit[0]]
+            first = [int(a) for a, b in obs if b == pid]
+            assert map_point[i] == (first[0] if first else -1)
+        else:
+            assert match_num[i] == -1 and map_point[i] == -1
+            x, y = kps["x"][i], kps["y"][i]
+            d = f(depth[int(y), int(x)]) * cam[4]
+            p = [f(f(x - cam[0]) * d) * inv_fx, f(f(y - cam[1]) * d) * inv_fy, d]
+            for r in range(3):
+                want = f(f(f(T[r, 0] * p[0]) + f(f(T[r, 1] * p[1]) + f(T[r, 2] * p[2]))) + T[r, 3])
+                assert world[i, r] == want
