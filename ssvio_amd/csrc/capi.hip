@@ -176,6 +176,11 @@ struct ssvio_orb {
     std::vector<uint2> h_raw; std::vector<int> h_rawCount, h_cellIni; std::vector<uint2> h_sel; std::vector<int> h_selCount;
     bool hostRawValid = false;
     std::vector<uint8_t> stageIn;      // packed copy of a strided input frame
+    // host entry points: k_describe stores a second copy of its outputs straight into this pinned, device-mapped area (keypoints,
+    // then descriptors), so a call needs no copy commands and one stream wait (a copy to pinned memory costs more than k_describe)
+    uint8_t* h_landing = nullptr; uint8_t* d_landing = nullptr; size_t landingCap = 0;
+    ssvio_keypoint* hostKp = nullptr; uint8_t* hostDesc = nullptr;      // set around one call; device addresses inside d_landing
+    uint8_t* h_inMapped = nullptr; uint8_t* d_inMapped = nullptr; size_t inMappedCap = 0;   // small inputs: k_level0 reads the frame from mapped host memory
     KernelProfiler prof; std::string profOnly;
     std::unique_ptr<WorkerPool> pool;
     int lastBatch = 0;
@@ -189,7 +194,7 @@ static void orb_free_buffers(ssvio_orb* h)
     dfree(h->d_in); dfree(h->d_pyr); dfree(h->d_blur); dfree(h->d_tabs);
     dfree(h->d_raw); dfree(h->d_rawCount); dfree(h->d_cellIni); dfree(h->d_kval); dfree(h->d_kord); dfree(h->d_knode);
     dfree(h->d_sel); dfree(h->d_selCount); dfree(h->d_kpCount); dfree(h->d_kpOut); dfree(h->d_desc); dfree(h->d_qtNode);
-    hfree(h->h_kpCount);
+    hfree(h->h_kpCount); hfree(h->h_landing); h->landingCap = 0; hfree(h->h_inMapped); h->inMappedCap = 0;
     h->batchCap = 0; h->inBytes = 0; h->haveResults = false;
     ++h->allocGen;                                   // a captured graph holds the old addresses
 }
@@ -408,7 +413,7 @@ static int orb_enqueue(ssvio_orb* h, int batch)
     {
         ProfScope p(h->prof, "k_describe", s);
         launch_describe(h->d_pyr, h->d_blur, g.frameBytes, h->kl, h->d_sel, h->d_selCount, h->kpCap, h->kpCap, h->d_kpOut, h->d_desc,
-                        h->d_kpCount, h->d_kpCountHost, batch, s);
+                        h->d_kpCount, h->d_kpCountHost, h->hostKp, h->hostDesc, batch, s);
     }
     SSVIO_HIP(hipGetLastError());                                 // a refused launch configuration shows up only here
     return SSVIO_OK;
@@ -430,7 +435,7 @@ static int orb_run(ssvio_orb* h, int batch, bool wait = true)
     hipStream_t s = h->stream;
     h->hostRawValid = false;
     bool launched = false;
-    if (graphs_enabled() && !h->hostQuadtree && !h->prof.enabled && !h->graphFailed) {
+    if (graphs_enabled() && !h->hostQuadtree && !h->prof.enabled && !h->graphFailed && !h->hostKp) {
         if (!h->gexec || h->gBatch != batch || h->gGen != h->allocGen) {
             if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
             quadtree_prepare();                                   // function attributes are set outside the capture
@@ -655,8 +660,29 @@ int ssvio_orb_extract_batch(ssvio_orb* h, const uint8_t* imgs, int batch, int ch
     int rc = orb_ensure(h, width, height, batch, (size_t)batch * rowBytes * height);
     if (rc) return rc;
     const PyramidGeom& g = h->geom;
-    // continuous frames (the usual cv::Mat) are one copy each; strided rows (an ROI) are packed on the host first, because a
-    // 2-D copy from pageable memory costs a transfer per row
+    // Small inputs (a frame or a few): the rows are packed by the host into pinned, device-mapped memory and k_level0 reads them from
+    // there -- no copy command, and a strided cv::Mat ROI costs nothing extra.  Larger batches: one copy per frame; strided rows are
+    // packed on the host first, because a 2-D copy from pageable memory costs a transfer per row.
+    const size_t inBytes = (size_t)batch * rowBytes * height;
+    static const bool noMapped = getenv("SSVIO_NO_MAPPED_INPUT") != nullptr;
+    const bool mappedIn = !noMapped && inBytes <= ((size_t)4 << 20);
+    const uint8_t* d_src = h->d_in;
+    if (mappedIn) {
+        if (inBytes > h->inMappedCap) {
+            SSVIO_HIP(hipStreamSynchronize(h->stream));
+            hfree(h->h_inMapped); h->inMappedCap = 0; h->d_inMapped = nullptr;
+            SSVIO_HIP(hipHostMalloc((void**)&h->h_inMapped, inBytes, hipHostMallocMapped));
+            SSVIO_HIP(hipHostGetDevicePointer((void**)&h->d_inMapped, h->h_inMapped, 0));
+            h->inMappedCap = inBytes;
+        }
+        for (int f = 0; f < batch; ++f) {
+            const uint8_t* src = imgs + (size_t)f * frame_stride;
+            uint8_t* dst = h->h_inMapped + (size_t)f * rowBytes * height;
+            if ((size_t)stride == rowBytes) memcpy(dst, src, rowBytes * height);
+            else for (int y = 0; y < height; ++y) memcpy(dst + (size_t)y * rowBytes, src + (size_t)y * stride, rowBytes);
+        }
+        d_src = h->d_inMapped;
+    } else
     for (int f = 0; f < batch; ++f) {
         const uint8_t* src = imgs + (size_t)f * frame_stride;
         if ((size_t)stride != rowBytes) {
@@ -669,17 +695,46 @@ int ssvio_orb_extract_batch(ssvio_orb* h, const uint8_t* imgs, int batch, int ch
     }
     {
         ProfScope p(h->prof, channels == 3 ? "k_rgb2gray" : "k_copy_gray", h->stream);
-        if (channels == 3) launch_rgb2gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
+        if (channels == 3) launch_rgb2gray(d_src, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
                                   h->d_rawCount, batch * kMaxLevels, h->d_cellIni, batch * g.cellsPerFrame, h->stream);
-        else launch_copy_gray(h->d_in, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
+        else launch_copy_gray(d_src, width, height, (int)rowBytes, rowBytes * height, batch, h->d_pyr + g.lv[0].offset, g.frameBytes, g.lv[0].pitch,
                                   h->d_rawCount, batch * kMaxLevels, h->d_cellIni, batch * g.cellsPerFrame, h->stream);
         SSVIO_HIP(hipGetLastError());
     }
-    rc = orb_run(h, batch);
+    // Results come back with the kernels: k_describe also stores every frame's slot range into mapped host memory, the host waits
+    // once and copies out what the counts say (a second device trip after reading the counts costs a wait more).
+    const size_t kpBytes = align256((size_t)batch * h->kpCap * sizeof(ssvio_keypoint)), dBytes = (size_t)batch * h->kpCap * 32;
+    if (!kps || !desc || kpBytes + dBytes > ((size_t)64 << 20)) {
+        rc = orb_run(h, batch);
+        if (rc) return rc;
+        rc = ssvio_orb_fetch_results(h, batch, kps, desc, cap, n);
+        h->prof.resolve();
+        return rc;
+    }
+    if (kpBytes + dBytes > h->landingCap) {
+        SSVIO_HIP(hipStreamSynchronize(h->stream));
+        hfree(h->h_landing); h->landingCap = 0; h->d_landing = nullptr;
+        SSVIO_HIP(hipHostMalloc((void**)&h->h_landing, kpBytes + dBytes, hipHostMallocMapped));
+        SSVIO_HIP(hipHostGetDevicePointer((void**)&h->d_landing, h->h_landing, 0));
+        h->landingCap = kpBytes + dBytes;
+    }
+    h->hostKp = (ssvio_keypoint*)h->d_landing; h->hostDesc = h->d_landing + kpBytes;
+    rc = orb_run(h, batch, false);
+    h->hostKp = nullptr; h->hostDesc = nullptr;
     if (rc) return rc;
-    rc = ssvio_orb_fetch_results(h, batch, kps, desc, cap, n);
-    h->prof.resolve();
-    return rc;
+    rc = orb_wait(h);
+    if (rc) return rc;
+    for (int f = 0; f < batch; ++f) {
+        const int c = h->h_kpCount[f];
+        if (c > cap) { set_error("frame %d has %d keypoints, caller capacity is %d", f, c, cap); return SSVIO_ERR_CAPACITY; }
+    }
+    for (int f = 0; f < batch; ++f) {
+        const int c = h->h_kpCount[f];
+        n[f] = c;
+        memcpy(kps + (size_t)f * cap, h->h_landing + (size_t)f * h->kpCap * sizeof(ssvio_keypoint), (size_t)c * sizeof(ssvio_keypoint));
+        memcpy(desc + (size_t)f * cap * 32, h->h_landing + kpBytes + (size_t)f * h->kpCap * 32, (size_t)c * 32);
+    }
+    return SSVIO_OK;
 }
 
 int ssvio_orb_extract(ssvio_orb* h, const uint8_t* gray, int width, int height, int stride,

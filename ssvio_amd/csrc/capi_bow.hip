@@ -48,14 +48,40 @@ static void bow_sort(ssvio_matcher* m, int setStrideRows, const int* d_counts, i
 
 // transform the rows of `nsets` descriptor sets; per-feature results land at rowBase + set * setStrideRows + i
 static void bow_run(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* d_desc, int setStrideRows, const int* d_counts, int nsets,
-                    int maxRows, int levelsup, size_t rowBase)
+                    int maxRows, int levelsup, size_t rowBase, bool toHost = false)
 {
     BowArgs a{};
     a.v = vocab_dev(v); a.nidLevel = v->L - levelsup;
     a.desc = (const uint4*)d_desc; a.setStrideRows = setStrideRows; a.counts = d_counts; a.nsets = nsets; a.maxRows = maxRows;
     a.word = m->d_bowWord + rowBase; a.node = m->d_bowNode + rowBase; a.weight = m->d_bowWeight + rowBase; a.gnode = m->d_gnode + rowBase;
+    if (toHost) {      // only gnode feeds later kernels: the three per-feature results go straight to mapped host memory (bow_host_area)
+        a.word = (int32_t*)m->d_bowm + rowBase; a.node = (int32_t*)m->d_bowm + m->bowmRows + rowBase;
+        a.weight = (double*)(m->d_bowm + 8 * m->bowmRows) + rowBase;
+    }
     ProfScope p(m->prof, "k_bow_transform", m->stream);
     launch_bow_transform(a, maxRows, m->stream);
+}
+
+// mapped host area for the per-feature transform results of `rows` features: [rows] word, [rows] node, [rows] weight
+static int bow_host_area(ssvio_matcher* m, size_t rows)
+{
+    if (16 * rows > m->bowmCap) {
+        SSVIO_HIP(hipStreamSynchronize(m->stream));
+        hfree(m->h_bowm); m->bowmCap = 0; m->d_bowm = nullptr;
+        const size_t want = 16 * (rows + rows / 4);
+        SSVIO_HIP(hipHostMalloc((void**)&m->h_bowm, want, hipHostMallocMapped));
+        SSVIO_HIP(hipHostGetDevicePointer((void**)&m->d_bowm, m->h_bowm, 0));
+        m->bowmCap = want;
+    }
+    m->bowmRows = rows;
+    return SSVIO_OK;
+}
+
+static void bow_host_copy(const ssvio_matcher* m, size_t base, int rows, int32_t* word, int32_t* node, double* weight)
+{
+    if (word) memcpy(word, (const int32_t*)m->h_bowm + base, (size_t)rows * 4);
+    if (node) memcpy(node, (const int32_t*)m->h_bowm + m->bowmRows + base, (size_t)rows * 4);
+    if (weight) memcpy(weight, (const double*)(m->h_bowm + 8 * m->bowmRows) + base, (size_t)rows * 8);
 }
 
 extern "C" {
@@ -125,19 +151,15 @@ int ssvio_bow_transform(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* d
     if (!desc || stride < 32) { set_error("bad descriptor matrix"); return SSVIO_ERR_INVALID; }
     SSVIO_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
-    size_t qcap = m->qRows * 32;
-    rc = grow(m->d_q, qcap, (size_t)n * 32, s); if (rc) return rc; m->qRows = qcap / 32;
     rc = bow_grow(m, (size_t)n); if (rc) return rc;
-    rc = upload_rows(m->d_q, desc, n, stride, m->stageQ, s); if (rc) return rc;
-    const int counts[2] = {n, 0};
-    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    bow_run(m, v, m->d_q, 0, m->d_counts2, 1, n, levelsup, 0);
+    rc = bow_host_area(m, (size_t)n); if (rc) return rc;
+    const uint8_t* d_rows; const uint8_t* d_none;
+    rc = stage_pair(m, desc, n, stride, desc, 0, 32, &d_rows, &d_none); if (rc) return rc;
+    m->h_counts2[0] = n; m->h_counts2[1] = 0;
+    bow_run(m, v, d_rows, 0, m->d_counts2m, 1, n, levelsup, 0, true);
     SSVIO_HIP(hipGetLastError());
-    if (word) SSVIO_HIP(hipMemcpyAsync(word, m->d_bowWord, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    if (node) SSVIO_HIP(hipMemcpyAsync(node, m->d_bowNode, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    if (weight) SSVIO_HIP(hipMemcpyAsync(weight, m->d_bowWeight, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     SSVIO_HIP(hipStreamSynchronize(s));
+    bow_host_copy(m, 0, n, word, node, weight);
     m->prof.resolve();
     m->lastBowQ = n; m->lastBowT = 0;
     return SSVIO_OK;
@@ -156,47 +178,47 @@ int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, i
     if (cap < nq) { set_error("output capacity %d < %d query rows", cap, nq); return SSVIO_ERR_CAPACITY; }
     SSVIO_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
-    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
-    rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
-    rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
     rc = bow_grow(m, (size_t)nq + nt); if (rc) return rc;
     rc = grow(m->d_cand, m->candCap, (size_t)nq, s); if (rc) return rc;
     rc = grow(m->d_keepNode, m->keepNodeCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_out, m->outCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
-    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
-    rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
-    const int counts[2] = {nq, nt};
-    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
-    bow_run(m, v, m->d_q, 0, m->d_counts2, 1, nq, levelsup, 0);               // ComputeBoWVector(desp1), :68
-    bow_run(m, v, m->d_t, 0, m->d_counts2 + 1, 1, nt, levelsup, (size_t)nq);  // ComputeBoWVector(desp2), :69
+    // no copy commands and one wait: descriptors (small sets), counts, per-feature transform results and the match list all live
+    // in mapped host memory that the kernels read / write directly
+    rc = bow_host_area(m, (size_t)nq + nt); if (rc) return rc;
+    rc = ensure_result(m, (size_t)nq * sizeof(ssvio_dmatch)); if (rc) return rc;
+    const uint8_t* d_q; const uint8_t* d_t;
+    rc = stage_pair(m, q, nq, qstride, t, nt, tstride, &d_q, &d_t); if (rc) return rc;
+    m->h_counts2[0] = nq; m->h_counts2[1] = nt;
+    *(volatile int*)m->h_result = 0;
+    const int* cq = m->d_counts2m; const int* ct = m->d_counts2m + 1;
+    ssvio_dmatch* outTo = (ssvio_dmatch*)(m->d_resultm + 16); int* noutTo = (int*)m->d_resultm;
+    bow_run(m, v, d_q, 0, cq, 1, nq, levelsup, 0, true);               // ComputeBoWVector(desp1), :68
+    bow_run(m, v, d_t, 0, ct, 1, nt, levelsup, (size_t)nq, true);      // ComputeBoWVector(desp2), :69
     if (std::max(nq, nt) <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED")) {
-        bow_sort(m, 0, m->d_counts2, 1, nq, 0);
-        bow_sort(m, 0, m->d_counts2 + 1, 1, nt, (size_t)nq);
+        bow_sort(m, 0, cq, 1, nq, 0);
+        bow_sort(m, 0, ct, 1, nt, (size_t)nq);
         SortedMatchArgs g{};
-        g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t;
+        g.qdesc = (const uint4*)d_q; g.tdesc = (const uint4*)d_t;
         g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx + nq; g.tSortedNode = m->d_sortNode + nq;
-        g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
+        g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = cq; g.tcounts = ct; g.pairs = nullptr;
         g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq; g.maxT = nt;
-        g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
+        g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = outTo; g.nout = noutTo;
         ProfScope p(m->prof, "k_match_sorted", s);
         launch_match_sorted(g, nq, nt, 1, s);
         SSVIO_HIP(hipGetLastError());
     } else {                                                           // sets beyond the LDS sort: wave per query over all train rows
         GroupedArgs g{};
-        g.qdesc = (const uint4*)m->d_q; g.tdesc = (const uint4*)m->d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + nq;
-        g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = m->d_counts2; g.tcounts = m->d_counts2 + 1; g.pairs = nullptr;
+        g.qdesc = (const uint4*)d_q; g.tdesc = (const uint4*)d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + nq;
+        g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = cq; g.tcounts = ct; g.pairs = nullptr;
         g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq; g.maxT = nt;
-        g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = m->d_out; g.nout = m->d_nout;
+        g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = outTo; g.nout = noutTo;
         ProfScope p(m->prof, "k_match_grouped", s);
         launch_match_grouped(g, nq, 1, s);
         SSVIO_HIP(hipGetLastError());
     }
-    int cnt = 0;
-    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
     SSVIO_HIP(hipStreamSynchronize(s));
-    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+    const int got = *(const volatile int*)m->h_result;
+    const int cnt = std::min(std::max(got, 0), nq);
+    if (cnt > 0) memcpy(out, m->h_result + 16, (size_t)cnt * sizeof(ssvio_dmatch));
     *n = cnt;
     m->prof.resolve();
     m->lastBowQ = nq; m->lastBowT = nt;
@@ -212,12 +234,7 @@ int ssvio_bow_last_transform(ssvio_matcher* m, int side, int32_t* word, int32_t*
     if (n) *n = rows;
     if (rows == 0) return SSVIO_OK;
     if (cap < rows) { set_error("capacity %d < %d rows", cap, rows); return SSVIO_ERR_CAPACITY; }
-    SSVIO_HIP(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    if (word) SSVIO_HIP(hipMemcpyAsync(word, m->d_bowWord + base, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
-    if (node) SSVIO_HIP(hipMemcpyAsync(node, m->d_bowNode + base, (size_t)rows * 4, hipMemcpyDeviceToHost, s));
-    if (weight) SSVIO_HIP(hipMemcpyAsync(weight, m->d_bowWeight + base, (size_t)rows * 8, hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipStreamSynchronize(s));
+    bow_host_copy(m, base, rows, word, node, weight);                  // the last host call left them in mapped host memory
     return SSVIO_OK;
 }
 

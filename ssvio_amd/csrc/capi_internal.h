@@ -25,6 +25,11 @@ struct ssvio_matcher {
     uint8_t* d_q = nullptr; size_t qRows = 0;
     uint8_t* d_t = nullptr; size_t tRows = 0;
     int* d_counts2 = nullptr;            // {nq, nt} of the single-pair entry points
+    // single-pair host entry points: counts and results live in pinned, device-mapped host memory that the kernels read / write
+    // directly -- no copy commands, one stream wait per call (a small copy to or from pinned memory costs more than the kernels)
+    int* h_counts2 = nullptr; int* d_counts2m = nullptr;                                  // {nq, nt} and its device address
+    uint8_t* h_result = nullptr; uint8_t* d_resultm = nullptr; size_t resultCap = 0;      // {count, pad to 16 B, rows}
+    uint8_t* h_descm = nullptr; uint8_t* d_descm = nullptr; size_t descmCap = 0;          // small sets: query rows, then train rows, packed by the host
     uint2* d_partial = nullptr; size_t partialCap = 0;
     uint2* d_partialRev = nullptr; size_t partialRevCap = 0;
     ssvio_dmatch* d_out = nullptr; size_t outCap = 0;
@@ -39,6 +44,9 @@ struct ssvio_matcher {
     int32_t* d_keepNode = nullptr; size_t keepNodeCap = 0;
     int32_t* d_sortIdx = nullptr; size_t sortIdxCap = 0; int32_t* d_sortNode = nullptr; size_t sortNodeCap = 0;
     int lastBowQ = 0, lastBowT = 0;
+    // host entry points: k_bow_transform stores word / node / weight straight into mapped host memory ([rows] int32, [rows] int32,
+    // [rows] double; query rows first, then train rows), from where ssvio_bow_last_transform serves them without touching the GPU
+    uint8_t* h_bowm = nullptr; uint8_t* d_bowm = nullptr; size_t bowmCap = 0; size_t bowmRows = 0;
     // behind the matcher (f2, f3)
     uint8_t* d_frameIn = nullptr; size_t frameInCap = 0;      // uploaded matches / keypoints / depth of the host entry points
     uint8_t* d_frameOut = nullptr; size_t frameOutCap = 0;    // assembled lists
@@ -64,3 +72,8 @@ template <typename T> inline int grow(T*& p, size_t& cap, size_t need, hipStream
 inline int mt_check(ssvio_matcher* m) { if (!m) { set_error("null matcher handle"); return SSVIO_ERR_INVALID; } return SSVIO_OK; }
 int upload_rows(uint8_t* dst, const uint8_t* src, int n, int stride, std::vector<uint8_t>& staging, hipStream_t s);   // capi_match.hip
 int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs);                                                   // capi_match.hip
+// descriptor rows of a single pair on the device: small sets are packed into mapped host memory that the kernels read directly,
+// larger ones are copied into d_q / d_t (capi_match.hip)
+int stage_pair(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, const uint8_t** d_q, const uint8_t** d_t);
+// mapped host landing area for {count, pad to 16 B, rows} of at least rowBytes (capi_match.hip)
+int ensure_result(ssvio_matcher* m, size_t rowBytes);

@@ -44,7 +44,8 @@ int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs)
 // shared driver: descriptors on the device; pairs == nullptr means the single pair (0,0)
 static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
                      const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts,
-                     const int* d_pairs, int npairs, int maxQ, int maxT, int mode)
+                     const int* d_pairs, int npairs, int maxQ, int maxT, int mode,
+                     ssvio_dmatch* outTo = nullptr, int* noutTo = nullptr, int32_t* rawTo = nullptr)
 {
     hipStream_t s = m->stream;
     const int maxRows = std::max(maxQ, maxT);
@@ -68,7 +69,7 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
     f.partial = m->d_partial; f.nChunks = nChunks; f.maxRows = maxRows;
     f.qcounts = d_qcounts; f.tcounts = d_tcounts; f.pairs = d_pairs;
     f.mode = mode; f.threshold = m->threshold; f.nnRatio = m->nnRatio;
-    f.out = m->d_out; f.nout = m->d_nout; f.raw = m->d_raw;
+    f.out = outTo ? outTo : m->d_out; f.nout = noutTo ? noutTo : m->d_nout; f.raw = rawTo ? rawTo : m->d_raw;
     if (mode == SSVIO_MODE_CROSSCHECK) {
         int nChunksR, chunkRowsR;
         pick_chunks(maxT, maxQ, npairs, nChunksR, chunkRowsR);
@@ -94,6 +95,47 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
     return SSVIO_OK;
 }
 
+int stage_pair(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, const uint8_t** d_q, const uint8_t** d_t)
+{
+    hipStream_t s = m->stream;
+    static const bool noMapped = getenv("SSVIO_NO_MAPPED_INPUT") != nullptr;
+    if (!noMapped && nq + nt <= 4096) {
+        // small sets (a frame pair): the host packs the rows into mapped memory and the kernels read them from there (every row crosses
+        // the bus a handful of times, which is still cheaper than two copy commands)
+        const size_t toff = align256((size_t)nq * 32), need = toff + (size_t)nt * 32;
+        if (need > m->descmCap) {
+            SSVIO_HIP(hipStreamSynchronize(s));
+            hfree(m->h_descm); m->descmCap = 0; m->d_descm = nullptr;
+            SSVIO_HIP(hipHostMalloc((void**)&m->h_descm, 2 * need, hipHostMallocMapped));
+            SSVIO_HIP(hipHostGetDevicePointer((void**)&m->d_descm, m->h_descm, 0));
+            m->descmCap = 2 * need;
+        }
+        if (qstride == 32) memcpy(m->h_descm, q, (size_t)nq * 32); else for (int i = 0; i < nq; ++i) memcpy(m->h_descm + (size_t)i * 32, q + (size_t)i * qstride, 32);
+        if (tstride == 32) memcpy(m->h_descm + toff, t, (size_t)nt * 32); else for (int i = 0; i < nt; ++i) memcpy(m->h_descm + toff + (size_t)i * 32, t + (size_t)i * tstride, 32);
+        *d_q = m->d_descm; *d_t = m->d_descm + toff;
+        return SSVIO_OK;
+    }
+    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
+    int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
+    rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
+    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
+    rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
+    *d_q = m->d_q; *d_t = m->d_t;
+    return SSVIO_OK;
+}
+
+int ensure_result(ssvio_matcher* m, size_t rowBytes)
+{
+    if (16 + rowBytes <= m->resultCap) return SSVIO_OK;
+    SSVIO_HIP(hipStreamSynchronize(m->stream));
+    hfree(m->h_result); m->resultCap = 0; m->d_resultm = nullptr;
+    const size_t want = 16 + rowBytes + rowBytes / 4;
+    SSVIO_HIP(hipHostMalloc((void**)&m->h_result, want, hipHostMallocMapped));
+    SSVIO_HIP(hipHostGetDevicePointer((void**)&m->d_resultm, m->h_result, 0));
+    m->resultCap = want;
+    return SSVIO_OK;
+}
+
 // host-pointer single pair
 static int match_host(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, int mode,
                       ssvio_dmatch* out, int cap, int* n, int32_t* idx, int32_t* d1, int32_t* d2)
@@ -108,27 +150,25 @@ static int match_host(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, c
     if (mode != 3 && cap < nq) { set_error("output capacity %d < %d query rows", cap, nq); return SSVIO_ERR_CAPACITY; }
     SSVIO_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
-    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
-    int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
-    rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
-    rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
-    rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
-    const int counts[2] = {nq, nt};
-    SSVIO_HIP(hipMemcpyAsync(m->d_counts2, counts, sizeof counts, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipStreamSynchronize(s));                                // `counts` is a stack array
-    rc = match_run(m, m->d_q, 0, m->d_counts2, m->d_t, 0, m->d_counts2 + 1, nullptr, 1, nq, nt, mode);
-    if (rc) return rc;
+    const uint8_t* d_qrows; const uint8_t* d_trows;
+    int rc = stage_pair(m, q, nq, qstride, t, nt, tstride, &d_qrows, &d_trows); if (rc) return rc;
+    // one wait per call and no copy commands: the kernels read the counts from, and write the count and the rows to, mapped host memory
     const int maxRows = std::max(nq, nt);
+    const size_t rowBytes = mode == 3 ? (size_t)3 * maxRows * sizeof(int32_t) : (size_t)maxRows * sizeof(ssvio_dmatch);
+    rc = ensure_result(m, rowBytes); if (rc) return rc;
+    m->h_counts2[0] = nq; m->h_counts2[1] = nt;
+    *(volatile int*)m->h_result = 0;
+    rc = match_run(m, d_qrows, 0, m->d_counts2m, d_trows, 0, m->d_counts2m + 1, nullptr, 1, nq, nt, mode,
+                   (ssvio_dmatch*)(m->d_resultm + 16), (int*)m->d_resultm, (int32_t*)(m->d_resultm + 16));
+    if (rc) return rc;
+    SSVIO_HIP(hipStreamSynchronize(s));
     if (mode == 3) {
-        std::vector<int32_t> raw((size_t)3 * maxRows);
-        SSVIO_HIP(hipMemcpyAsync(raw.data(), m->d_raw, raw.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipStreamSynchronize(s));
+        const int32_t* raw = (const int32_t*)(m->h_result + 16);
         for (int i = 0; i < nq; ++i) { if (idx) idx[i] = raw[i]; if (d1) d1[i] = raw[maxRows + i]; if (d2) d2[i] = raw[2 * (size_t)maxRows + i]; }
     } else {
-        int cnt = 0;
-        SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipStreamSynchronize(s));
-        if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+        const int got = *(const volatile int*)m->h_result;
+        const int cnt = std::min(std::max(got, 0), nq);
+        if (cnt > 0) memcpy(out, m->h_result + 16, (size_t)cnt * sizeof(ssvio_dmatch));
         if (n) *n = cnt;
     }
     m->prof.resolve();
@@ -146,8 +186,13 @@ int ssvio_matcher_create(int threshold, float nn_ratio, int device, ssvio_matche
     SSVIO_HIP(hipSetDevice(device));
     ssvio_matcher* m = new ssvio_matcher();
     m->device = device; m->threshold = threshold; m->nnRatio = nn_ratio;
-    if (hipStreamCreateWithFlags(&m->own, hipStreamNonBlocking) != hipSuccess || hipMalloc(&m->d_counts2, 2 * sizeof(int)) != hipSuccess) {
-        set_error("cannot create HIP stream / allocate"); delete m; return SSVIO_ERR_HIP;
+    if (hipStreamCreateWithFlags(&m->own, hipStreamNonBlocking) != hipSuccess || hipMalloc(&m->d_counts2, 2 * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&m->h_counts2, 2 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&m->d_counts2m, m->h_counts2, 0) != hipSuccess) {
+        set_error("cannot create HIP stream / allocate");
+        if (m->own) (void)hipStreamDestroy(m->own);
+        dfree(m->d_counts2); hfree(m->h_counts2);
+        delete m; return SSVIO_ERR_HIP;
     }
     m->stream = m->own;
     *out = m;
@@ -165,6 +210,7 @@ void ssvio_matcher_destroy(ssvio_matcher* m)
     dfree(m->d_p3d); dfree(m->d_p2d); dfree(m->d_cand); dfree(m->d_keep);
     dfree(m->d_bowWord); dfree(m->d_bowNode); dfree(m->d_bowWeight); dfree(m->d_gnode); dfree(m->d_keepNode); dfree(m->d_sortIdx); dfree(m->d_sortNode);
     dfree(m->d_frameIn); dfree(m->d_frameOut); dfree(m->d_table);
+    hfree(m->h_counts2); hfree(m->h_result); hfree(m->h_descm); hfree(m->h_bowm);
     if (m->own) (void)hipStreamDestroy(m->own);
     delete m;
 }

@@ -185,6 +185,8 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const 
 // sel: per level lists {x | y<<16, level | resp<<8} at f*selPerFrame + selBase[l]; selCount[f][kMaxLevels]
 void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl,
                      const uint2* sel, const int* selCount, int selPerFrame, int cap, ssvio_keypoint* kpOut, uint8_t* desc,
-                     int* kpCount, int* kpCountHost /* device view of pinned host memory */, int batch, hipStream_t s);
+                     int* kpCount, int* kpCountHost /* device view of pinned host memory */,
+                     ssvio_keypoint* kpHost, uint8_t* descHost /* optional second copy of the outputs in mapped host memory */,
+                     int batch, hipStream_t s);
 
 }  // namespace ssvio

@@ -661,7 +661,8 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
                                                   size_t pyrFrameBytes, KLevels kl, const uint2* __restrict__ sel,
                                                   const int* __restrict__ selCount, int selPerFrame, int cap,
                                                   ssvio_keypoint* __restrict__ kpOut, uint8_t* __restrict__ desc, int* __restrict__ kpCount,
-                                                  int* __restrict__ kpCountHost, int blocksPerFrame, int batch)
+                                                  int* __restrict__ kpCountHost, ssvio_keypoint* __restrict__ kpHost, uint8_t* __restrict__ descHost,
+                                                  int blocksPerFrame, int batch)
 {
     int frame, blk;
     xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
@@ -767,6 +768,7 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
     if (!live) return;
     const size_t o = (size_t)frame * cap + k;
     if (sl < 8) ((uint32_t*)(desc + o * 32))[sl] = myword;
+    if (descHost && sl < 8) ((uint32_t*)(descHost + o * 32))[sl] = myword;      // host entry points: a second copy straight into mapped host memory
     if (sl == 0) {
         ssvio_keypoint kp;
         const float scale = L.scale;
@@ -775,16 +777,17 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
         kp.size = (float)L.kpSize;
         kp.angle = angle; kp.response = (float)resp; kp.octave = level; kp.class_id = -1;
         kpOut[o] = kp;
+        if (kpHost) kpHost[o] = kp;
     }
 }
 
 void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl,
                      const uint2* sel, const int* selCount, int selPerFrame, int cap, ssvio_keypoint* kpOut, uint8_t* desc,
-                     int* kpCount, int* kpCountHost, int batch, hipStream_t s)
+                     int* kpCount, int* kpCountHost, ssvio_keypoint* kpHost, uint8_t* descHost, int batch, hipStream_t s)
 {
     const int bpf = (cap + kDescThreads / 32 - 1) / (kDescThreads / 32);
     hipLaunchKernelGGL(k_describe, dim3(bpf * batch), dim3(kDescThreads), 0, s, pyr, blur, pyrFrameBytes, kl, sel, selCount, selPerFrame,
-                       cap, kpOut, desc, kpCount, kpCountHost, bpf, batch);
+                       cap, kpOut, desc, kpCount, kpCountHost, kpHost, descHost, bpf, batch);
 }
 
 }  // namespace ssvio

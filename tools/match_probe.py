@@ -46,5 +46,23 @@ t1 = time.perf_counter()
 for _ in range(50): fm.MatchByBruteForce(db, da)
 t2 = time.perf_counter()
 print("host path: Extract(VGA, 1000) %.1f us per call, MatchByBruteForce(%dx%d) %.1f us per call" % ((t1 - t0) / 50 * 1e6, len(db), len(da), (t2 - t1) / 50 * 1e6))
+from ssvio_amd.vocabulary import Vocabulary
+par, vdesc, vw = synth.vocabulary_tables_full(3, 10, 5)
+voc = Vocabulary(10, 5, par, vdesc, vw)
+fd = ssvio_amd.FeatureMatching(voc, {"Threshold": 50, "NNRatio": 0.6})
+for _ in range(3): fd.MatchByDBoW(db, da)
+t0 = time.perf_counter()
+for _ in range(50): ok, md = fd.MatchByDBoW(db, da)
+t1 = time.perf_counter()
+print("host path: MatchByDBoW(%dx%d, vocabulary k=10 L=5, fills mBowVec / mFeatVec) %.1f us per call, %d matches" % (len(db), len(da), (t1 - t0) / 50 * 1e6, len(md)))
+import ctypes as C
+out = np.zeros(len(db), L.DM_DTYPE); n = C.c_int(0)
+call = lambda: L.lib().ssvio_match_dbow(fd._h, voc.handle(0), L.ptr(db), len(db), 32, L.ptr(da), len(da), 32, 4, L.ptr(out), len(out), C.byref(n))
+for _ in range(3): call()
+t0 = time.perf_counter()
+for _ in range(50): call()
+t1 = time.perf_counter()
+print("host path: ssvio_match_dbow through the C ABI alone %.1f us per call (%d matches)" % ((t1 - t0) / 50 * 1e6, n.value))
+fd.close(); voc.close()
 ex.close()
 fm.close()
