@@ -337,3 +337,38 @@ print("graph ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSVIO_GRAPH="1"), capture_output=True, text=True, timeout=200)
     assert r.returncode == 0 and "graph ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_copy_path_of_the_host_entry_points_gives_the_same_results():
+    """Small host inputs are read from device-mapped memory by default; SSVIO_NO_MAPPED_INPUT=1 (read once per process, hence
+    the child) sends the same calls down the copy path that large inputs take.  Both against the oracle, strided ROI included."""
+    import os, subprocess, sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import ssvio_amd as S
+from ssvio_amd import synth
+from oracle import oracle as O
+g = S.ORBextractor(700, 1.2, 8, 20, 7); c = O.Extractor(700, 1.2, 8, 20, 7)
+a, b = synth.frame_pair(77, 240, 320)
+wide = np.zeros((240, 400), np.uint8); wide[:, 40:360] = a
+ka, da = g.Extract(wide[:, 40:360]); rk, rd = c.extract(a)
+assert np.array_equal(ka.view(np.uint8), rk.view(np.uint8)) and np.array_equal(da, rd)
+kb, db = g.Extract(b)
+fm = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
+u8 = lambda x: np.ascontiguousarray(x).view(np.uint8)
+assert np.array_equal(u8(fm.MatchByBruteForce(db, da)[1]), u8(O.match_bruteforce(db, da)))
+assert np.array_equal(u8(fm.MatchByKnnRatio(db, da)[1]), u8(O.match_knn2_ratio(db, da, 50, 0.6)))
+assert np.array_equal(u8(fm.MatchByCrossCheck(db, da)[1]), u8(O.match_crosscheck(db, da)))
+wd = np.zeros((len(db), 48), np.uint8); wd[:, :32] = db
+assert np.array_equal(u8(fm.MatchByBruteForce(wd[:, :32], da)[1]), u8(O.match_bruteforce(db, da)))
+par, desc, w = synth.vocabulary_tables(5, 10, 4, stop_p=0.02)
+v = S.Vocabulary(10, 4, par, desc, w); ov = O.Vocabulary(10, 4, par, desc, w, v.word)
+fd = S.FeatureMatching(v, {"Threshold": 50, "NNRatio": 0.6})
+assert np.array_equal(u8(fd.MatchByDBoW(db, da)[1]), u8(O.match_dbow(ov, db, da, 50, 0.6, 4)))
+rw, rn, rwt = ov.transform(db, 4)
+assert fd.mFeatVec1_ == S.Vocabulary.feature_vector(rn, rwt)
+print("copy path ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSVIO_NO_MAPPED_INPUT="1"), capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0 and "copy path ok" in r.stdout, r.stderr[-2000:]
