@@ -14,13 +14,16 @@ static int cam_dev(const ssvio_camera* cam, int w, int h, int stride_px, FrameCa
 }
 
 
-// carve the assembled-list block of the handle into its seven arrays + counts
-static int assemble_outputs(ssvio_matcher* m, int npairs, int maxRows, AssembleArgs& a)
+// carve the assembled-list block into its seven arrays + counts: in HBM (batched, device-resident form) or, for the host entry
+// point, in mapped host memory that k_assemble stores to directly (`host` then receives the host view of the same block)
+static int assemble_outputs(ssvio_matcher* m, int npairs, int maxRows, AssembleArgs& a, uint8_t** host = nullptr)
 {
     const size_t rows = (size_t)npairs * maxRows;
     const size_t s3 = align256(rows * 12), s2 = align256(rows * 8), sm = align256(rows * 16), sc = align256((size_t)npairs * 8);
-    int rc = grow(m->d_frameOut, m->frameOutCap, 4 * s3 + s2 + 2 * sm + sc, m->stream); if (rc) return rc;
-    uint8_t* p = m->d_frameOut;
+    int rc;
+    uint8_t* p;
+    if (host) { rc = grow_mapped(m->h_fout, m->d_fout, m->foutCap, 4 * s3 + s2 + 2 * sm + sc, m->stream); if (rc) return rc; p = m->d_fout; *host = m->h_fout; }
+    else { rc = grow(m->d_frameOut, m->frameOutCap, 4 * s3 + s2 + 2 * sm + sc, m->stream); if (rc) return rc; p = m->d_frameOut; }
     a.last3d = (float*)p; p += s3; a.cur3d = (float*)p; p += s3; a.edgeLast3d = (float*)p; p += s3; a.edgeCur3d = (float*)p; p += s3;
     a.cur2d = (float*)p; p += s2; a.preGood = (ssvio_dmatch*)p; p += sm; a.finalGood = (ssvio_dmatch*)p; p += sm; a.counts = (int*)p;
     return SSVIO_OK;
@@ -76,46 +79,39 @@ int ssvio_assemble_correspondences(ssvio_matcher* m, const ssvio_dmatch* matches
         }
     SSVIO_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
+    // matches, keypoints and counts go into mapped host memory (read across the bus by one workgroup), the two depth planes are copied
+    // (only ~nm pixels of each are read, but they sit in pageable memory), all seven lists come back through mapped memory: one wait
     const int kpStride = std::max(std::max(nlast, ncur), 1);
     const size_t depthPx = (size_t)h * stride_px;
     const size_t mb = align256((size_t)nm * 16), kb = align256((size_t)2 * kpStride * sizeof(ssvio_keypoint)), db = align256(2 * depthPx * 2);
-    rc = grow(m->d_frameIn, m->frameInCap, mb + kb + db + 256, s); if (rc) return rc;
-    uint8_t* d_m = m->d_frameIn; uint8_t* d_k = d_m + mb; uint8_t* d_d = d_k + kb; int* d_c = (int*)(d_d + db);   // {nm, ncur, nlast}
-    SSVIO_HIP(hipMemcpyAsync(d_m, matches, (size_t)nm * 16, hipMemcpyHostToDevice, s));
-    if (ncur) SSVIO_HIP(hipMemcpyAsync(d_k, cur_kps, (size_t)ncur * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));       // set 0 = current
-    if (nlast) SSVIO_HIP(hipMemcpyAsync(d_k + (size_t)kpStride * sizeof(ssvio_keypoint), last_kps, (size_t)nlast * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));
+    rc = grow_mapped(m->h_fin, m->d_fin, m->finCap, mb + kb + 256, s); if (rc) return rc;
+    rc = grow(m->d_frameIn, m->frameInCap, db, s); if (rc) return rc;
+    memcpy(m->h_fin, matches, (size_t)nm * 16);
+    if (ncur) memcpy(m->h_fin + mb, cur_kps, (size_t)ncur * sizeof(ssvio_keypoint));                                           // set 0 = current
+    if (nlast) memcpy(m->h_fin + mb + (size_t)kpStride * sizeof(ssvio_keypoint), last_kps, (size_t)nlast * sizeof(ssvio_keypoint));
+    int* cnts = (int*)(m->h_fin + mb + kb); cnts[0] = nm; cnts[1] = ncur; cnts[2] = nlast;
+    uint8_t* d_d = m->d_frameIn;
     SSVIO_HIP(hipMemcpyAsync(d_d, cur_depth, depthPx * 2, hipMemcpyHostToDevice, s));
     SSVIO_HIP(hipMemcpyAsync(d_d + depthPx * 2, last_depth, depthPx * 2, hipMemcpyHostToDevice, s));
-    const int cnts[3] = {nm, ncur, nlast};
-    SSVIO_HIP(hipMemcpyAsync(d_c, cnts, sizeof cnts, hipMemcpyHostToDevice, s));
-    SSVIO_HIP(hipStreamSynchronize(s));                             // `cnts` is a stack array
+    const int* d_c = (const int*)(m->d_fin + mb + kb);
     AssembleArgs a{};
-    a.matches = (const ssvio_dmatch*)d_m; a.nmatches = d_c; a.maxRows = nm; a.pairs = nullptr;
-    a.kps = (const ssvio_keypoint*)d_k; a.kpStride = kpStride; a.kpCounts = d_c + 1;
+    a.matches = (const ssvio_dmatch*)m->d_fin; a.nmatches = d_c; a.maxRows = nm; a.pairs = nullptr;
+    a.kps = (const ssvio_keypoint*)(m->d_fin + mb); a.kpStride = kpStride; a.kpCounts = d_c + 1;
     a.depth = (const uint16_t*)d_d; a.depthFrameStride = depthPx; a.cam = c;
-    rc = assemble_outputs(m, 1, nm, a); if (rc) return rc;
+    uint8_t* hostOut = nullptr;
+    rc = assemble_outputs(m, 1, nm, a, &hostOut); if (rc) return rc;
     {
         ProfScope p(m->prof, "k_assemble", s);
         launch_assemble(a, 1, s);
         SSVIO_HIP(hipGetLastError());
     }
-    int got[2] = {0, 0};
-    SSVIO_HIP(hipMemcpyAsync(got, a.counts, sizeof got, hipMemcpyDeviceToHost, s));
     SSVIO_HIP(hipStreamSynchronize(s));
-    const size_t np = (size_t)got[0], nf = (size_t)got[1];
-    if (np) {
-        SSVIO_HIP(hipMemcpyAsync(last3d, a.last3d, np * 12, hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(cur2d, a.cur2d, np * 8, hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(cur3d, a.cur3d, np * 12, hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(pre_good, a.preGood, np * 16, hipMemcpyDeviceToHost, s));
-    }
-    if (nf) {
-        SSVIO_HIP(hipMemcpyAsync(edge_last3d, a.edgeLast3d, nf * 12, hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(edge_cur3d, a.edgeCur3d, nf * 12, hipMemcpyDeviceToHost, s));
-        SSVIO_HIP(hipMemcpyAsync(final_good, a.finalGood, nf * 16, hipMemcpyDeviceToHost, s));
-    }
-    SSVIO_HIP(hipStreamSynchronize(s));
-    *n_pre = got[0]; *n_final = got[1];
+    auto hv = [&](const void* dev) { return hostOut + ((const uint8_t*)dev - m->d_fout); };          // host view of a carved array
+    const int* got = (const int*)hv(a.counts);
+    const size_t np = (size_t)std::min(std::max(got[0], 0), nm), nf = (size_t)std::min(std::max(got[1], 0), nm);
+    memcpy(last3d, hv(a.last3d), np * 12); memcpy(cur2d, hv(a.cur2d), np * 8); memcpy(cur3d, hv(a.cur3d), np * 12); memcpy(pre_good, hv(a.preGood), np * 16);
+    memcpy(edge_last3d, hv(a.edgeLast3d), nf * 12); memcpy(edge_cur3d, hv(a.edgeCur3d), nf * 12); memcpy(final_good, hv(a.finalGood), nf * 16);
+    *n_pre = (int)np; *n_final = (int)nf;
     m->prof.resolve();
     return SSVIO_OK;
 }
@@ -224,36 +220,39 @@ int ssvio_manage_map_points(ssvio_matcher* m, const ssvio_keypoint* kps, int nkp
     }
     SSVIO_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
+    // keypoints, matches and observation pairs go into mapped host memory, the depth plane is copied, the three per-keypoint arrays
+    // come back through mapped memory: one wait
     const size_t kb = align256((size_t)nkp * sizeof(ssvio_keypoint)), db = align256((size_t)h * stride_px * 2),
                  mb = align256((size_t)std::max(nm, 1) * 16), ob = align256((size_t)std::max(nobs, 1) * 8);
     const size_t ib = align256((size_t)nkp * 4);
-    rc = grow(m->d_frameIn, m->frameInCap, kb + db + mb + ob, s); if (rc) return rc;
-    rc = grow(m->d_frameOut, m->frameOutCap, 2 * ib + (size_t)nkp * 12, s); if (rc) return rc;
+    rc = grow_mapped(m->h_fin, m->d_fin, m->finCap, kb + mb + ob, s); if (rc) return rc;
+    rc = grow_mapped(m->h_fout, m->d_fout, m->foutCap, 2 * ib + (size_t)nkp * 12, s); if (rc) return rc;
+    rc = grow(m->d_frameIn, m->frameInCap, db, s); if (rc) return rc;
     rc = grow(m->d_table, m->tableCap, (size_t)2 * nkp, s); if (rc) return rc;       // [0, nkp): matches by queryIdx, [nkp, 2 nkp): observations by point id
-    uint8_t* d_k = m->d_frameIn; uint8_t* d_d = d_k + kb; uint8_t* d_m = d_d + db; uint8_t* d_o = d_m + mb;
-    SSVIO_HIP(hipMemcpyAsync(d_k, kps, (size_t)nkp * sizeof(ssvio_keypoint), hipMemcpyHostToDevice, s));
+    memcpy(m->h_fin, kps, (size_t)nkp * sizeof(ssvio_keypoint));
+    if (nm) memcpy(m->h_fin + kb, last_match_vec, (size_t)nm * 16);
+    if (nobs) memcpy(m->h_fin + kb + mb, obs, (size_t)nobs * 8);
+    const uint8_t* d_k = m->d_fin; const uint8_t* d_m = d_k + kb; const uint8_t* d_o = d_m + mb; uint8_t* d_d = m->d_frameIn;
     SSVIO_HIP(hipMemcpyAsync(d_d, depth, (size_t)h * stride_px * 2, hipMemcpyHostToDevice, s));
-    if (nm) SSVIO_HIP(hipMemcpyAsync(d_m, last_match_vec, (size_t)nm * 16, hipMemcpyHostToDevice, s));
-    if (nobs) SSVIO_HIP(hipMemcpyAsync(d_o, obs, (size_t)nobs * 8, hipMemcpyHostToDevice, s));
     SSVIO_HIP(hipMemsetAsync(m->d_table, 0xFF, (size_t)2 * nkp * 4, s));
     {
         ProfScope p(m->prof, "k_first_index", s);
         launch_first_index((const int32_t*)d_m, nm, 4, 0, m->d_table, nkp, s);             // InMatchVec, src/Map.cpp:151-162
         launch_first_index((const int32_t*)d_o, nobs, 2, 1, m->d_table + nkp, nkp, s);     // GetMapPointID, src/Frame.cpp:138-147
+        SSVIO_HIP(hipGetLastError());
     }
     ManageXform T; std::memcpy(T.m, world_trans, sizeof T.m);
-        SSVIO_HIP(hipGetLastError());
-    int32_t* d_mn = (int32_t*)m->d_frameOut; int32_t* d_mp = (int32_t*)(m->d_frameOut + ib); float* d_w = (float*)(m->d_frameOut + 2 * ib);
+    int32_t* d_mn = (int32_t*)m->d_fout; int32_t* d_mp = (int32_t*)(m->d_fout + ib); float* d_w = (float*)(m->d_fout + 2 * ib);
     {
         ProfScope p(m->prof, "k_manage", s);
         launch_manage((const ssvio_keypoint*)d_k, nkp, (const uint16_t*)d_d, c, T, (const ssvio_dmatch*)d_m, m->d_table,
                       (const int32_t*)d_o, m->d_table + nkp, nkp, d_mn, d_mp, d_w, s);
         SSVIO_HIP(hipGetLastError());
     }
-    SSVIO_HIP(hipMemcpyAsync(match_num, d_mn, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipMemcpyAsync(map_point, d_mp, (size_t)nkp * 4, hipMemcpyDeviceToHost, s));
-    SSVIO_HIP(hipMemcpyAsync(world, d_w, (size_t)nkp * 12, hipMemcpyDeviceToHost, s));
     SSVIO_HIP(hipStreamSynchronize(s));
+    memcpy(match_num, m->h_fout, (size_t)nkp * 4);
+    memcpy(map_point, m->h_fout + ib, (size_t)nkp * 4);
+    memcpy(world, m->h_fout + 2 * ib, (size_t)nkp * 12);
     m->prof.resolve();
     return SSVIO_OK;
 }

@@ -51,6 +51,9 @@ struct ssvio_matcher {
     uint8_t* d_frameIn = nullptr; size_t frameInCap = 0;      // uploaded matches / keypoints / depth of the host entry points
     uint8_t* d_frameOut = nullptr; size_t frameOutCap = 0;    // assembled lists
     uint32_t* d_table = nullptr; size_t tableCap = 0;
+    // host entry points behind the matcher: small inputs (matches, keypoints, counts) and all outputs live in mapped host memory
+    uint8_t* h_fin = nullptr; uint8_t* d_fin = nullptr; size_t finCap = 0;
+    uint8_t* h_fout = nullptr; uint8_t* d_fout = nullptr; size_t foutCap = 0;
     std::vector<uint8_t> stageQ, stageT;              // packed copies of strided descriptor rows
     std::vector<int32_t> h_pairs;                     // what d_pairs holds (an unchanged pair list is not uploaded again)
     KernelProfiler prof; std::string profOnly;
@@ -65,6 +68,20 @@ template <typename T> inline int grow(T*& p, size_t& cap, size_t need, hipStream
     dfree(p);
     need += need / 4;
     SSVIO_HIP(hipMalloc(&p, need * sizeof(T)));
+    cap = need;
+    return SSVIO_OK;
+}
+
+// (re)allocates a pinned, device-mapped host block of at least `need` bytes; waits for the stream before the old one goes
+inline int grow_mapped(uint8_t*& h, uint8_t*& d, size_t& cap, size_t need, hipStream_t s)
+{
+    if (need <= cap) return SSVIO_OK;
+    SSVIO_HIP(hipStreamSynchronize(s));
+    if (h) { (void)hipHostFree(h); h = nullptr; }
+    d = nullptr; cap = 0;
+    need += need / 4;
+    SSVIO_HIP(hipHostMalloc((void**)&h, need, hipHostMallocMapped));
+    SSVIO_HIP(hipHostGetDevicePointer((void**)&d, h, 0));
     cap = need;
     return SSVIO_OK;
 }

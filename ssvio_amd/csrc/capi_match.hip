@@ -210,7 +210,7 @@ void ssvio_matcher_destroy(ssvio_matcher* m)
     dfree(m->d_p3d); dfree(m->d_p2d); dfree(m->d_cand); dfree(m->d_keep);
     dfree(m->d_bowWord); dfree(m->d_bowNode); dfree(m->d_bowWeight); dfree(m->d_gnode); dfree(m->d_keepNode); dfree(m->d_sortIdx); dfree(m->d_sortNode);
     dfree(m->d_frameIn); dfree(m->d_frameOut); dfree(m->d_table);
-    hfree(m->h_counts2); hfree(m->h_result); hfree(m->h_descm); hfree(m->h_bowm);
+    hfree(m->h_counts2); hfree(m->h_result); hfree(m->h_descm); hfree(m->h_bowm); hfree(m->h_fin); hfree(m->h_fout);
     if (m->own) (void)hipStreamDestroy(m->own);
     delete m;
 }

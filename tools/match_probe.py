@@ -63,6 +63,21 @@ t0 = time.perf_counter()
 for _ in range(50): call()
 t1 = time.perf_counter()
 print("host path: ssvio_match_dbow through the C ABI alone %.1f us per call (%d matches)" % ((t1 - t0) / 50 * 1e6, n.value))
+# the steps behind the matcher, host buffers in and out (python wrapper overhead included)
+from oracle import oracle as O
+depth_a, depth_b = synth.depth_image(12, 480, 640), synth.depth_image(13, 480, 640)
+cam = O.camera(320.5, 240.5, 500.0, 500.0, 10.0)
+ok, mb = fm.MatchByBruteForce(db, da)
+def timeit(f, n=30):
+    for _ in range(3): f()
+    t = time.perf_counter()
+    for _ in range(n): r = f()
+    return (time.perf_counter() - t) / n * 1e6, r
+t_as, c = timeit(lambda: fm.AssembleCorrespondences(mb, ka, depth_a, kb, depth_b, cam))
+t_tr, trk = timeit(lambda: fm.TrackMapPoints(mb, c["final_good"]))
+obs = np.stack([np.arange(len(ka)), np.arange(len(ka))], 1).astype(np.int32)
+t_mg, _ = timeit(lambda: fm.ManageMapPoints(kb, depth_b, cam, np.eye(4), trk, obs))
+print("host path: AssembleCorrespondences(%d matches, two 640x480 depth planes) %.1f us, TrackMapPoints %.1f us, ManageMapPoints(%d keypoints) %.1f us per call" % (len(mb), t_as, t_tr, len(kb), t_mg))
 fd.close(); voc.close()
 ex.close()
 fm.close()
