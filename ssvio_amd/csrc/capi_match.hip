@@ -280,37 +280,41 @@ int ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, i
     if (cap < nq) { set_error("output capacity %d < %d reference points", cap, nq); return SSVIO_ERR_CAPACITY; }
     SSVIO_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
+    int rc = grow(m->d_cand, m->candCap, (size_t)nq, s); if (rc) return rc;
+    rc = grow(m->d_keep, m->keepCap, (size_t)nq, s); if (rc) return rc;
+    // every wave scans all nt projected points and many train rows: inputs are copied to HBM (reading them across the bus once per
+    // wave would cost more than the copies); the match list is stored straight to mapped host memory, so the call waits once
     size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
-    int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
+    rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
     rc = grow(m->d_t, tcap, (size_t)std::max(nt, 1) * 32, s); if (rc) return rc; m->tRows = tcap / 32;
     rc = grow(m->d_p3d, m->p3dCap, (size_t)nq * 3, s); if (rc) return rc;
     rc = grow(m->d_p2d, m->p2dCap, (size_t)std::max(nt, 1) * 2, s); if (rc) return rc;
-    rc = grow(m->d_cand, m->candCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_keep, m->keepCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_out, m->outCap, (size_t)nq, s); if (rc) return rc;
-    rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
     rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
     SSVIO_HIP(hipMemcpyAsync(m->d_p3d, p3d, (size_t)nq * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     if (nt > 0) {
         rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
         SSVIO_HIP(hipMemcpyAsync(m->d_p2d, p2d, (size_t)nt * 2 * sizeof(double), hipMemcpyHostToDevice, s));
     }
+    const uint8_t* d_q = m->d_q; const uint8_t* d_t = m->d_t;
+    const double* d_p3 = m->d_p3d; const double* d_p2 = m->d_p2d;
+    rc = ensure_result(m, (size_t)nq * sizeof(ssvio_dmatch)); if (rc) return rc;
+    *(volatile int*)m->h_result = 0;
     ProjectArgs a{};
-    a.p3d = m->d_p3d; a.qdesc = (const uint4*)m->d_q; a.nq = nq; a.p2d = m->d_p2d; a.tdesc = (const uint4*)m->d_t; a.nt = nt;
+    a.p3d = d_p3; a.qdesc = (const uint4*)d_q; a.nq = nq; a.p2d = d_p2; a.tdesc = (const uint4*)d_t; a.nt = nt;
     a.radian = radian;
     for (int i = 0; i < 9; ++i) { a.K[i] = K[i]; a.R[i] = R[i]; }
     for (int i = 0; i < 3; ++i) a.t[i] = tr[i];
     a.threshold = m->threshold; a.nnRatio = m->nnRatio;
-    a.cand = m->d_cand; a.keep = m->d_keep; a.out = m->d_out; a.nout = m->d_nout;
+    a.cand = m->d_cand; a.keep = m->d_keep; a.out = (ssvio_dmatch*)(m->d_resultm + 16); a.nout = (int*)m->d_resultm;
     {
         ProfScope p(m->prof, "k_match_project", s);
         launch_project(a, s);
         SSVIO_HIP(hipGetLastError());
     }
-    int cnt = 0;
-    SSVIO_HIP(hipMemcpyAsync(&cnt, m->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
     SSVIO_HIP(hipStreamSynchronize(s));
-    if (cnt > 0) SSVIO_HIP(hipMemcpy(out, m->d_out, (size_t)cnt * sizeof(ssvio_dmatch), hipMemcpyDeviceToHost));
+    const int got = *(const volatile int*)m->h_result;
+    const int cnt = std::min(std::max(got, 0), nq);
+    if (cnt > 0) memcpy(out, m->h_result + 16, (size_t)cnt * sizeof(ssvio_dmatch));
     *n = cnt;
     m->prof.resolve();
     return SSVIO_OK;
