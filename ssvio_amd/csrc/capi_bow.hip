@@ -178,27 +178,35 @@ int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, i
     if (cap < nq) { set_error("output capacity %d < %d query rows", cap, nq); return SSVIO_ERR_CAPACITY; }
     SSVIO_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
-    rc = bow_grow(m, (size_t)nq + nt); if (rc) return rc;
     rc = grow(m->d_cand, m->candCap, (size_t)nq, s); if (rc) return rc;
     rc = grow(m->d_keepNode, m->keepNodeCap, (size_t)nq, s); if (rc) return rc;
     // no copy commands and one wait: descriptors (small sets), counts, per-feature transform results and the match list all live
     // in mapped host memory that the kernels read / write directly
-    rc = bow_host_area(m, (size_t)nq + nt); if (rc) return rc;
     rc = ensure_result(m, (size_t)nq * sizeof(ssvio_dmatch)); if (rc) return rc;
     const uint8_t* d_q; const uint8_t* d_t;
     rc = stage_pair(m, q, nq, qstride, t, nt, tstride, &d_q, &d_t); if (rc) return rc;
+    // When both sets sit in one block (the mapped staging area), they are two sets of one launch: set stride = their distance in rows.
+    const bool oneBlock = d_t > d_q && (size_t)(d_t - d_q) % 32 == 0 && (size_t)(d_t - d_q) / 32 >= (size_t)nq && (size_t)(d_t - d_q) / 32 < (size_t)nq + 64;
+    const size_t tBase = oneBlock ? (size_t)(d_t - d_q) / 32 : (size_t)nq;      // where the train side's per-feature rows start
+    rc = bow_grow(m, tBase + nt); if (rc) return rc;
+    rc = bow_host_area(m, tBase + nt); if (rc) return rc;
     m->h_counts2[0] = nq; m->h_counts2[1] = nt;
     *(volatile int*)m->h_result = 0;
     const int* cq = m->d_counts2m; const int* ct = m->d_counts2m + 1;
     ssvio_dmatch* outTo = (ssvio_dmatch*)(m->d_resultm + 16); int* noutTo = (int*)m->d_resultm;
-    bow_run(m, v, d_q, 0, cq, 1, nq, levelsup, 0, true);               // ComputeBoWVector(desp1), :68
-    bow_run(m, v, d_t, 0, ct, 1, nt, levelsup, (size_t)nq, true);      // ComputeBoWVector(desp2), :69
-    if (std::max(nq, nt) <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED")) {
-        bow_sort(m, 0, cq, 1, nq, 0);
-        bow_sort(m, 0, ct, 1, nt, (size_t)nq);
+    const bool sorted = std::max(nq, nt) <= kBowSortMax && !getenv("SSVIO_DBOW_UNSORTED");
+    if (oneBlock) {
+        bow_run(m, v, d_q, (int)tBase, cq, 2, std::max(nq, nt), levelsup, 0, true);      // ComputeBoWVector(desp1), (desp2), :68-69
+        if (sorted) bow_sort(m, (int)tBase, cq, 2, std::max(nq, nt), 0);
+    } else {
+        bow_run(m, v, d_q, 0, cq, 1, nq, levelsup, 0, true);
+        bow_run(m, v, d_t, 0, ct, 1, nt, levelsup, tBase, true);
+        if (sorted) { bow_sort(m, 0, cq, 1, nq, 0); bow_sort(m, 0, ct, 1, nt, tBase); }
+    }
+    if (sorted) {
         SortedMatchArgs g{};
         g.qdesc = (const uint4*)d_q; g.tdesc = (const uint4*)d_t;
-        g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx + nq; g.tSortedNode = m->d_sortNode + nq;
+        g.qSortedIdx = m->d_sortIdx; g.qSortedNode = m->d_sortNode; g.tSortedIdx = m->d_sortIdx + tBase; g.tSortedNode = m->d_sortNode + tBase;
         g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = cq; g.tcounts = ct; g.pairs = nullptr;
         g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq; g.maxT = nt;
         g.cand = m->d_cand; g.keep = m->d_keepNode; g.out = outTo; g.nout = noutTo;
@@ -207,7 +215,7 @@ int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, i
         SSVIO_HIP(hipGetLastError());
     } else {                                                           // sets beyond the LDS sort: wave per query over all train rows
         GroupedArgs g{};
-        g.qdesc = (const uint4*)d_q; g.tdesc = (const uint4*)d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + nq;
+        g.qdesc = (const uint4*)d_q; g.tdesc = (const uint4*)d_t; g.qgnode = m->d_gnode; g.tgnode = m->d_gnode + tBase;
         g.qSetStrideRows = 0; g.tSetStrideRows = 0; g.qcounts = cq; g.tcounts = ct; g.pairs = nullptr;
         g.threshold = m->threshold; g.nnRatio = m->nnRatio; g.maxRows = nq; g.maxT = nt;
         g.cand = m->d_cand; g.keepNode = m->d_keepNode; g.out = outTo; g.nout = noutTo;
@@ -221,7 +229,7 @@ int ssvio_match_dbow(ssvio_matcher* m, const ssvio_vocab* v, const uint8_t* q, i
     if (cnt > 0) memcpy(out, m->h_result + 16, (size_t)cnt * sizeof(ssvio_dmatch));
     *n = cnt;
     m->prof.resolve();
-    m->lastBowQ = nq; m->lastBowT = nt;
+    m->lastBowQ = nq; m->lastBowT = nt; m->lastBowTBase = tBase;
     return SSVIO_OK;
 }
 
@@ -230,7 +238,7 @@ int ssvio_bow_last_transform(ssvio_matcher* m, int side, int32_t* word, int32_t*
     if (mt_check(m)) return SSVIO_ERR_INVALID;
     if (side != 0 && side != 1) { set_error("side must be 0 (desp1) or 1 (desp2)"); return SSVIO_ERR_INVALID; }
     const int rows = side ? m->lastBowT : m->lastBowQ;
-    const size_t base = side ? (size_t)m->lastBowQ : 0;
+    const size_t base = side ? m->lastBowTBase : 0;
     if (n) *n = rows;
     if (rows == 0) return SSVIO_OK;
     if (cap < rows) { set_error("capacity %d < %d rows", cap, rows); return SSVIO_ERR_CAPACITY; }

@@ -43,7 +43,7 @@ struct ssvio_matcher {
     double* d_bowWeight = nullptr; size_t bowWeightCap = 0; int32_t* d_gnode = nullptr; size_t gnodeCap = 0;
     int32_t* d_keepNode = nullptr; size_t keepNodeCap = 0;
     int32_t* d_sortIdx = nullptr; size_t sortIdxCap = 0; int32_t* d_sortNode = nullptr; size_t sortNodeCap = 0;
-    int lastBowQ = 0, lastBowT = 0;
+    int lastBowQ = 0, lastBowT = 0; size_t lastBowTBase = 0;      // rows of the last host call's two sides; where the train side's results start
     // host entry points: k_bow_transform stores word / node / weight straight into mapped host memory ([rows] int32, [rows] int32,
     // [rows] double; query rows first, then train rows), from where ssvio_bow_last_transform serves them without touching the GPU
     uint8_t* h_bowm = nullptr; uint8_t* d_bowm = nullptr; size_t bowmCap = 0; size_t bowmRows = 0;
