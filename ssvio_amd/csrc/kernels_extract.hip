@@ -350,14 +350,19 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     {   // one queue reservation per wave
         const int lane = tid & 63;
         const int cnt = __popc(flags);
+        // inclusive scan over the wave in six DPP adds: shifts by 1, 2, 4, 8 inside the rows of 16, then lane 15 / lane 31 carried on
         int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int tt = __shfl_up(incl, o); if (lane >= o) incl += tt; }
-        const int tot = __shfl(incl, 63);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
         if (tot) {
             int base = 0;
             if (lane == 63) base = atomicAdd(&qn, tot);
-            base = __shfl(base, 63) + incl - cnt;
+            base = __builtin_amdgcn_readlane(base, 63) + incl - cnt;
             const int e0 = r0 * kFtPitch + 4 * qc;              // byte index of this thread's first quad in the score tile
             unsigned f = flags;
             while (f) {
