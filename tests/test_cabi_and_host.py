@@ -90,3 +90,19 @@ def test_host_quadtree_on_clustered_points(oracle):
         want, _ = oracle.distribute_octtree(xs, ys, resp, 0, 608, 0, 448, N)
         got = ssvio_amd.distribute_octtree(xs, ys, resp, 0, 608, 0, 448, N)
         assert np.array_equal(got, want), N
+
+
+def test_header_is_plain_c99_and_links_from_c(tmp_path):
+    """the boundary is a C ABI: include/ssvio_gpu.h compiles as C99 (-pedantic) and a C program links against the library"""
+    import subprocess
+    src = tmp_path / "c_abi.c"
+    src.write_text('#include "ssvio_gpu.h"\n'
+                   'int main(void) { ssvio_orb_params p = {1000, 1.2f, 8, 20, 7}; ssvio_orb* h = 0;\n'
+                   '  int rc = ssvio_orb_create(&p, 0, &h); if (rc == SSVIO_OK) ssvio_orb_destroy(h);\n'
+                   '  return (rc == SSVIO_OK || rc == SSVIO_ERR_NOGPU) && ssvio_last_error() != 0 ? 0 : 1; }\n')
+    lib = os.path.join(ROOT, "ssvio_amd")
+    exe = tmp_path / "c_abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", lib, "-lssvio_gpu", "-Wl,-rpath," + lib])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr           # without a GPU: SSVIO_ERR_NOGPU and a message, never a crash or a fallback
