@@ -163,6 +163,7 @@ struct ssvio_orb {
     size_t inBytes = 0;
     uint8_t* d_in = nullptr; uint8_t* d_pyr = nullptr; uint8_t* d_blur = nullptr; uint8_t* d_score = nullptr;
     int16_t* d_tabs = nullptr; std::vector<size_t> xTabOff, yTabOff, qTabOff; std::vector<char> quadOk; std::vector<int> resizeRows;
+    std::vector<char> fuse2;           // fuse2[l]: levels l and l + 1 can be built by one k_resize2 launch
     uint2* d_raw = nullptr; int* d_rawCount = nullptr; int* d_cellIni = nullptr;     // FAST output: unordered candidate lists
     uint32_t* d_kval = nullptr; uint32_t* d_kord = nullptr; uint32_t* d_knode = nullptr;   // quadtree per-key scratch
     uint2* d_sel = nullptr; int* d_selCount = nullptr;                                  // selected keypoints per level
@@ -237,9 +238,13 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
         // resize tables
         std::vector<int16_t> all;
         h->xTabOff.assign(g.nlevels, 0); h->yTabOff.assign(g.nlevels, 0); h->qTabOff.assign(g.nlevels, 0); h->quadOk.assign(g.nlevels, 0); h->resizeRows.assign(g.nlevels, 1);
+        h->fuse2.assign(g.nlevels + 1, 0);
         for (int l = 1; l < g.nlevels; ++l) {
             ResizeTabs t;
             build_resize_tabs(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h, t);
+            // the pair (l - 1, l) in one launch: neither level is the exact 2:1 INTER_AREA case and the tile slices fit
+            if (l >= 2 && h->quadOk[l - 1] != 2 && !t.area2)
+                h->fuse2[l - 1] = resize2_fits(t.xs.data(), t.ys.data(), g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h) ? 1 : 0;
             h->xTabOff[l] = all.size(); all.insert(all.end(), t.xs.begin(), t.xs.end());
             h->yTabOff[l] = all.size(); all.insert(all.end(), t.ys.begin(), t.ys.end());
             while (all.size() % 16) all.push_back(0);
@@ -378,9 +383,18 @@ static int orb_enqueue(ssvio_orb* h, int batch)
     const PyramidGeom& g = h->geom;
     hipStream_t s = h->stream;
     // d_rawCount / d_cellIni were cleared by k_level0
-    for (int l = 1; l < g.nlevels; ++l) {
+    // a frame or two per call: the chain of dependent launches is the cost, so two levels are built per launch where the tables allow
+    static const bool noFuse = getenv("SSVIO_NO_RESIZE2") != nullptr;
+    const bool fuse = !noFuse && batch <= 2;
+    for (int l = 1; l < g.nlevels;) {
         ProfScope p(h->prof, "k_resize", s);
-        launch_resize(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], h->qTabOff[l], (int)h->quadOk[l], h->resizeRows[l], batch, s);
+        if (fuse && l + 1 < g.nlevels && h->fuse2[l]) {
+            launch_resize2(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], h->xTabOff[l + 1], h->yTabOff[l + 1], batch, s);
+            l += 2;
+        } else {
+            launch_resize(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], h->qTabOff[l], (int)h->quadOk[l], h->resizeRows[l], batch, s);
+            l += 1;
+        }
     }
     {
         ProfScope p(h->prof, "k_fast", s);

@@ -171,6 +171,9 @@ void launch_rgb2gray(const uint8_t* src, int w, int h, int stride, size_t frameS
                      uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s);
 void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
                       uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s);
+bool resize2_fits(const int16_t* xsB, const int16_t* ysB, int wA, int hA, int wB, int hB);
+void launch_resize2(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int levelA, const int16_t* tabs,
+                    size_t xTabOffA, size_t yTabOffA, size_t xTabOffB, size_t yTabOffB, int batch, hipStream_t s);
 void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int level, const int16_t* tabs,
                    size_t xTabOff, size_t yTabOff, size_t quadTabOff, int mode /*0 generic, 1 quad, 2 area 2x2*/, int rows, int batch, hipStream_t s);
 // FAST: appends {key, val} per NMS survivor to the level's raw list; key = flags<<30 | cell<<12 | iy<<6 | ix

@@ -188,6 +188,112 @@ __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, 
     }
 }
 
+// Two levels per launch (small batches, where the chain of dependent launches is the cost): a workgroup owns a 64 x 16 tile of
+// level B = l + 1.  It first computes the slice of level A = l that the tile's taps touch (from level l - 1, same arithmetic as
+// k_resize) into LDS, stores the part of that slice it owns to HBM (ownership cuts level A along the first taps of the tile
+// borders, so every pixel of A is stored exactly once; the edge tiles add A's pad columns), then resizes its tile of B out of LDS.
+// Valid while the taps of 64 (16) consecutive outputs span at most kR2W (kR2H) source pixels, i.e. scale factors up to ~1.9; the
+// host checks that from the tables and falls back to one launch per level otherwise.
+constexpr int kR2TW = 64, kR2TH = 16, kR2W = 144, kR2H = 40;
+
+__device__ __forceinline__ int resize_px(const uint8_t* S0, const uint8_t* S1, const short4 tx, int b0, int b1)
+{
+    const int t0 = S0[tx.x] * tx.z + S0[tx.y] * tx.w;
+    const int t1 = S1[tx.x] * tx.z + S1[tx.y] * tx.w;
+    return ((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2) & 255;
+}
+
+__global__ __launch_bounds__(256) void k_resize2(uint8_t* __restrict__ pyr, size_t pyrFrameBytes,
+                                                 unsigned long long offS, int pitchS,
+                                                 unsigned long long offA, int pitchA, int wA, int hA,
+                                                 unsigned long long offB, int pitchB, int wB, int hB,
+                                                 const short4* __restrict__ xtA, const short4* __restrict__ ytA,
+                                                 const short4* __restrict__ xtB, const short4* __restrict__ ytB,
+                                                 int tilesX, int tilesY, int blocksPerFrame, int batch)
+{
+    __shared__ uint8_t lds[kR2H][kR2W];
+    int frame, blk;
+    xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
+    const int ty = blk / tilesX, tx = blk - ty * tilesX;
+    const bool firstX = tx == 0, lastX = tx == tilesX - 1, firstY = ty == 0, lastY = ty == tilesY - 1;
+    const int bx0 = tx * kR2TW, bx1 = min(bx0 + kR2TW, wB), by0 = ty * kR2TH, by1 = min(by0 + kR2TH, hB);
+    // slice of A: from the first tap of the tile's first output (pulled in for the pads' reflections at the right edge) to the
+    // last tap of its last output; the edge tiles reach A's own edges so that they can own (and pad) them
+    const int bxr = lastX ? max(0, min(bx0, wB - 1 - kPadX)) : bx0;
+    int ax0 = firstX ? 0 : xtB[bxr].x, ax1 = lastX ? wA - 1 : xtB[bx1 - 1].y;
+    if (lastX) ax0 = max(0, min(ax0, wA - 1 - kPadX));
+    const int ay0 = firstY ? 0 : ytB[by0].x, ay1 = lastY ? hA - 1 : ytB[by1 - 1].y;
+    const int RW = ax1 - ax0 + 1, RH = ay1 - ay0 + 1;
+    const uint8_t* S = pyr + (size_t)frame * pyrFrameBytes + offS;
+    uint8_t* A = pyr + (size_t)frame * pyrFrameBytes + offA;
+    uint8_t* B = pyr + (size_t)frame * pyrFrameBytes + offB;
+    for (int i = threadIdx.x; i < RW * RH; i += 256) {
+        const int ry = i / RW, rx = i - ry * RW;
+        const short4 tyA = ytA[ay0 + ry];
+        lds[ry][rx] = (uint8_t)resize_px(S + (size_t)tyA.x * pitchS, S + (size_t)tyA.y * pitchS, xtA[ax0 + rx], tyA.z, tyA.w);
+    }
+    __syncthreads();
+    {   // owned part of A, pad columns included on the edge tiles
+        const int ox0 = firstX ? -kPadX : xtB[bx0].x, ox1 = lastX ? wA + kPadX : xtB[bx1].x;      // [ox0, ox1)
+        const int oy0 = firstY ? 0 : ytB[by0].x, oy1 = lastY ? hA : ytB[by1].x;
+        const int OW = ox1 - ox0, OH = oy1 - oy0;
+        for (int i = threadIdx.x; i < OW * OH; i += 256) {
+            const int ry = i / OW, rx = i - ry * OW;
+            const int x = ox0 + rx, y = oy0 + ry;
+            A[(size_t)y * pitchA + x] = lds[y - ay0][refl_clamp(x, wA) - ax0];
+        }
+    }
+    {   // the tile of B out of LDS
+        const int px0 = firstX ? -kPadX : bx0, px1 = lastX ? wB + kPadX : bx1;
+        const int PW = px1 - px0, PH = by1 - by0;
+        for (int i = threadIdx.x; i < PW * PH; i += 256) {
+            const int ry = i / PW, rx = i - ry * PW;
+            const int x = px0 + rx, y = by0 + ry;
+            const short4 tyB = ytB[y];
+            short4 txB = xtB[refl_clamp(x, wB)];
+            txB.x -= (short)ax0; txB.y -= (short)ax0;
+            B[(size_t)y * pitchB + x] = (uint8_t)resize_px(lds[tyB.x - ay0], lds[tyB.y - ay0], txB, tyB.z, tyB.w);
+        }
+    }
+}
+
+// host check of k_resize2's slice bounds for the level pair (A from S, B from A); tables as built by build_resize_tabs
+bool resize2_fits(const int16_t* xsB, const int16_t* ysB, int wA, int hA, int wB, int hB)
+{
+    if (wA < 2 * kPadX + 2 || wB < 2 * kPadX + 2) return false;
+    const int tilesX = (wB + kR2TW - 1) / kR2TW, tilesY = (hB + kR2TH - 1) / kR2TH;
+    for (int tx = 0; tx < tilesX; ++tx) {
+        const int bx0 = tx * kR2TW, bx1 = std::min(bx0 + kR2TW, wB);
+        const bool lastX = tx == tilesX - 1;
+        const int bxr = lastX ? std::max(0, std::min(bx0, wB - 1 - kPadX)) : bx0;
+        int ax0 = tx == 0 ? 0 : xsB[4 * bxr], ax1 = lastX ? wA - 1 : xsB[4 * (bx1 - 1) + 1];
+        if (lastX) ax0 = std::max(0, std::min(ax0, wA - 1 - kPadX));
+        if (ax1 - ax0 + 1 > kR2W || ax1 < ax0) return false;
+        if (!lastX && (xsB[4 * bx1] > ax1 + 1 || xsB[4 * bx1] < ax0)) return false;     // the owned range lies inside the slice
+        for (int x = bxr; x < bx1; ++x) if (xsB[4 * x] < ax0 || xsB[4 * x + 1] > ax1) return false;
+    }
+    for (int ty = 0; ty < tilesY; ++ty) {
+        const int by0 = ty * kR2TH, by1 = std::min(by0 + kR2TH, hB);
+        const bool lastY = ty == tilesY - 1;
+        const int ay0 = ty == 0 ? 0 : ysB[4 * by0], ay1 = lastY ? hA - 1 : ysB[4 * (by1 - 1) + 1];
+        if (ay1 - ay0 + 1 > kR2H || ay1 < ay0) return false;
+        if (!lastY && (ysB[4 * by1] > ay1 + 1 || ysB[4 * by1] < ay0)) return false;
+        for (int y = by0; y < by1; ++y) if (ysB[4 * y] < ay0 || ysB[4 * y + 1] > ay1) return false;
+    }
+    return true;
+}
+
+void launch_resize2(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int levelA, const int16_t* tabs,
+                    size_t xTabOffA, size_t yTabOffA, size_t xTabOffB, size_t yTabOffB, int batch, hipStream_t s)
+{
+    const KLevel& S = kl.lv[levelA - 1]; const KLevel& A = kl.lv[levelA]; const KLevel& B = kl.lv[levelA + 1];
+    const int tilesX = (B.w + kR2TW - 1) / kR2TW, tilesY = (B.h + kR2TH - 1) / kR2TH;
+    hipLaunchKernelGGL(k_resize2, dim3(tilesX * tilesY * batch), dim3(256), 0, s, pyr, pyrFrameBytes, S.offset, S.pitch,
+                       A.offset, A.pitch, A.w, A.h, B.offset, B.pitch, B.w, B.h,
+                       (const short4*)(tabs + xTabOffA), (const short4*)(tabs + yTabOffA), (const short4*)(tabs + xTabOffB), (const short4*)(tabs + yTabOffB),
+                       tilesX, tilesY, tilesX * tilesY, batch);
+}
+
 void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int level, const int16_t* tabs,
                    size_t xTabOff, size_t yTabOff, size_t quadTabOff, int mode, int rows, int batch, hipStream_t s)
 {

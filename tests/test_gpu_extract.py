@@ -372,3 +372,21 @@ print("copy path ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSVIO_NO_MAPPED_INPUT="1"), capture_output=True, text=True, timeout=200)
     assert r.returncode == 0 and "copy path ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("w,h,sf,nl", [(640, 480, 1.2, 8), (333, 257, 1.5, 4), (500, 300, 1.9, 3), (400, 400, 2.0, 3), (317, 203, 1.1, 9)])
+def test_two_levels_per_launch_for_small_batches(mods, w, h, sf, nl):
+    """calls of one or two frames build two pyramid levels per launch (k_resize2) where the tables allow; larger batches one level
+    per launch: every level's bytes and the end results equal the oracle's either way (2.0 is the INTER_AREA case, never fused)"""
+    S, synth, O = mods
+    imgs = np.stack([synth.texture(300 + i, h, w) for i in range(3)])
+    g = S.ORBextractor(600, sf, nl, 20, 7); c = O.Extractor(600, sf, nl, 20, 7)
+    for batch in (1, 2, 3):
+        ks, ds, ns = g.extract_batch(imgs[:batch])
+        for f in range(batch):
+            rk, rd = c.extract(imgs[f])
+            assert ns[f] == len(rk) and np.array_equal(ks[f, :ns[f]].view(np.uint8), rk.view(np.uint8)) and np.array_equal(ds[f, :ns[f]], rd)
+            if f == batch - 1:
+                for l in range(nl):
+                    assert np.array_equal(g.debug_level_image(l, frame=f), c.level_image(l)), (batch, l)
+    g.close()
