@@ -383,11 +383,13 @@ static int orb_enqueue(ssvio_orb* h, int batch)
     const PyramidGeom& g = h->geom;
     hipStream_t s = h->stream;
     // d_rawCount / d_cellIni were cleared by k_level0
-    // a frame or two per call: the chain of dependent launches is the cost, so two levels are built per launch where the tables allow
+    // small launches (a frame or two per call, or the upper levels of a large frame): the chain of dependent launches is the cost,
+    // so two levels are built per launch where the tables allow.  Above ~600 k pixels per launch the streaming kernel's
+    // bandwidth wins (measured: 4K single frame 336 us unfused, 363 us with every pair fused).
     static const bool noFuse = getenv("SSVIO_NO_RESIZE2") != nullptr;
-    const bool fuse = !noFuse && batch <= 2;
     for (int l = 1; l < g.nlevels;) {
         ProfScope p(h->prof, "k_resize", s);
+        const bool fuse = !noFuse && (long)g.lv[l].w * g.lv[l].h * batch <= 600000;
         if (fuse && l + 1 < g.nlevels && h->fuse2[l]) {
             launch_resize2(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], h->xTabOff[l + 1], h->yTabOff[l + 1], batch, s);
             l += 2;

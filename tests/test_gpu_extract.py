@@ -376,8 +376,9 @@ print("copy path ok")
 
 @pytest.mark.parametrize("w,h,sf,nl", [(640, 480, 1.2, 8), (333, 257, 1.5, 4), (500, 300, 1.9, 3), (400, 400, 2.0, 3), (317, 203, 1.1, 9)])
 def test_two_levels_per_launch_for_small_batches(mods, w, h, sf, nl):
-    """calls of one or two frames build two pyramid levels per launch (k_resize2) where the tables allow; larger batches one level
-    per launch: every level's bytes and the end results equal the oracle's either way (2.0 is the INTER_AREA case, never fused)"""
+    """small launches build two pyramid levels at once (k_resize2) where the tables allow, larger ones (more frames, bigger levels)
+    one level per launch: every level's bytes and the end results equal the oracle's either way (2.0 is the INTER_AREA case,
+    never fused)"""
     S, synth, O = mods
     imgs = np.stack([synth.texture(300 + i, h, w) for i in range(3)])
     g = S.ORBextractor(600, sf, nl, 20, 7); c = O.Extractor(600, sf, nl, 20, 7)
