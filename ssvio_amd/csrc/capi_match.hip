@@ -51,6 +51,8 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
     const int maxRows = std::max(maxQ, maxT);
     int nChunks, chunkRows;
     pick_chunks(maxQ, maxT, npairs, nChunks, chunkRows);
+    const bool small = knn2_small_applies(maxQ, maxT, npairs), smallRev = knn2_small_applies(maxT, maxQ, npairs);
+    if (small) { nChunks = 1; chunkRows = maxT; }
     int rc = grow(m->d_partial, m->partialCap, (size_t)npairs * nChunks * maxRows, s); if (rc) return rc;
     rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
     if (mode == 3) { rc = grow(m->d_raw, m->rawCap, (size_t)npairs * 3 * maxRows, s); if (rc) return rc; }
@@ -62,7 +64,7 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
     a.nChunks = nChunks; a.chunkRows = chunkRows; a.partial = m->d_partial; a.maxRows = maxRows;
     {
         ProfScope p(m->prof, "k_hamming_knn2", s);
-        launch_knn2(a, maxQ, npairs, s);
+        if (small) launch_knn2_small(a, maxQ, npairs, s); else launch_knn2(a, maxQ, npairs, s);
         SSVIO_HIP(hipGetLastError());
     }
     FinalizeArgs f{};
@@ -73,6 +75,7 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
     if (mode == SSVIO_MODE_CROSSCHECK) {
         int nChunksR, chunkRowsR;
         pick_chunks(maxT, maxQ, npairs, nChunksR, chunkRowsR);
+        if (smallRev) { nChunksR = 1; chunkRowsR = maxQ; }
         rc = grow(m->d_partialRev, m->partialRevCap, (size_t)npairs * nChunksR * maxRows, s); if (rc) return rc;
         MatchArgs r = a;
         r.qdesc = (const uint4*)d_tdesc; r.tdesc = (const uint4*)d_qdesc;
@@ -81,7 +84,7 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
         r.nChunks = nChunksR; r.chunkRows = chunkRowsR; r.partial = m->d_partialRev;
         {
             ProfScope p(m->prof, "k_hamming_knn2", s);
-            launch_knn2(r, maxT, npairs, s);
+            if (smallRev) launch_knn2_small(r, maxT, npairs, s); else launch_knn2(r, maxT, npairs, s);
             SSVIO_HIP(hipGetLastError());
         }
         f.partialRev = m->d_partialRev; f.nChunksRev = nChunksR;

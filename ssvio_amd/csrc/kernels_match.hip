@@ -111,6 +111,71 @@ __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
     }
 }
 
+// Small single pairs (the per-frame call: ~1000 x 1000): the chunks of the train set are the 8 waves of one workgroup, which all
+// hold the same 64 queries (one per lane) and merge their two smallest keys through LDS -- no k_match_merge launch behind it.
+// Each wave stages 64 train rows at a time in its own LDS slice (no workgroup barrier in the loop) and reads them back as
+// wave-wide broadcasts like the kernel above.  Output: partial[pair][0][q], i.e. nChunks = 1.
+constexpr int kSmallWaves = 8;
+__global__ __launch_bounds__(64 * kSmallWaves) void k_hamming_knn2_small(MatchArgs a)
+{
+    __shared__ uint4 rows[kSmallWaves][64 * 2];
+    __shared__ uint2 keys[kSmallWaves][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pair = blockIdx.y;
+    const int qset = a.pairs ? a.pairs[2 * pair + a.swap] : 0;
+    const int tset = a.pairs ? a.pairs[2 * pair + 1 - a.swap] : 0;
+    const int nq = a.qcounts[qset], nt = a.tcounts[tset];
+    const int q0 = blockIdx.x * 64;
+    if (q0 >= nq) return;                                      // block-uniform
+    const uint4* Q = a.qdesc + (size_t)qset * a.qSetStrideRows * 2;
+    const uint4* T = a.tdesc + (size_t)tset * a.tSetStrideRows * 2;
+    const int qi = q0 + lane;
+    uint32_t q[1][8], k1[1] = {kKeyInit}, k2[1] = {kKeyInit};
+    {
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+        if (qi < nq) { lo = Q[(size_t)qi * 2]; hi = Q[(size_t)qi * 2 + 1]; }
+        q[0][0] = lo.x; q[0][1] = lo.y; q[0][2] = lo.z; q[0][3] = lo.w; q[0][4] = hi.x; q[0][5] = hi.y; q[0][6] = hi.z; q[0][7] = hi.w;
+    }
+    const int per = ((nt + kSmallWaves - 1) / kSmallWaves + 63) & ~63;            // rows per wave, a multiple of the 64-row tile
+    const int tBeg = min(w * per, nt), tEnd = min(tBeg + per, nt);
+    uint4* my = rows[w];
+    for (int t0 = tBeg; t0 < tEnd; t0 += 64) {
+        const int n = min(64, tEnd - t0);
+        if (lane < n) { my[2 * lane] = T[(size_t)(t0 + lane) * 2]; my[2 * lane + 1] = T[(size_t)(t0 + lane) * 2 + 1]; }
+        __builtin_amdgcn_wave_barrier();
+        if (n == 64) {
+#pragma unroll 4
+            for (int j = 0; j < 64; ++j) row_update<1>(q, k1, k2, my[2 * j], my[2 * j + 1], (uint32_t)(t0 + j));
+        } else {
+            for (int j = 0; j < n; ++j) row_update<1>(q, k1, k2, my[2 * j], my[2 * j + 1], (uint32_t)(t0 + j));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    keys[w][lane] = make_uint2(k1[0], k2[0]);
+    __syncthreads();
+    if (w == 0 && qi < nq) {
+        uint32_t m1 = kKeyInit, m2 = kKeyInit;
+#pragma unroll
+        for (int c = 0; c < kSmallWaves; ++c) {
+            const uint2 p = keys[c][lane];
+            m2 = umed3(m1, m2, p.x); m1 = min(m1, p.x);
+            m2 = umed3(m1, m2, p.y); m1 = min(m1, p.y);
+        }
+        a.partial[(size_t)pair * a.maxRows + qi] = make_uint2(m1, m2);
+    }
+}
+
+bool knn2_small_applies(int maxQ, int maxT, int npairs)
+{
+    static const bool off = getenv("SSVIO_NO_SMALL_MATCH") != nullptr;
+    return !off && npairs <= 2 && maxQ <= 2048 && maxT <= 4096;
+}
+
+void launch_knn2_small(const MatchArgs& a, int maxQ, int npairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hamming_knn2_small, dim3((maxQ + 63) / 64, npairs), dim3(64 * kSmallWaves), 0, s, a);
+}
+
 // R = 4 keeps LDS reads at a quarter of the VALU time; small query sets use fewer so that more workgroups exist
 int knn2_queries_per_lane(int maxQ)
 {

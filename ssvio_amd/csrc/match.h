@@ -108,6 +108,8 @@ void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, 
                   ssvio_dmatch* out, int* nout, hipStream_t s);
 
 void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);
+bool knn2_small_applies(int maxQ, int maxT, int npairs);                 // small single pairs: chunks = the waves of one workgroup, no merge launch
+void launch_knn2_small(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);   // writes partial[pair][q] (nChunks = 1, pair stride maxRows)
 int  knn2_queries_per_lane(int maxQ);       // R of k_hamming_knn2<R> for this many query rows (tuning knob: SSVIO_MATCH_R)
 void launch_finalize(const FinalizeArgs& a, int npairs, int maxQ, int maxT, hipStream_t s);
 
