@@ -8,6 +8,7 @@
 // over as arrays with SetVocabulary.  The QuickLZ-compressed stream and the YAML container are not read.  Without
 // a vocabulary MatchByDBoW returns false (lastStatus() tells why).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <fstream>
 #include <map>
@@ -198,12 +199,29 @@ private:
     {
         bv.clear(); fv.clear();
         const bool tf = weighting_ == 0 || weighting_ == 1, must = scoring_ != 5;
-        for (size_t i = 0; i < word.size(); ++i) {
-            if (!(weight[i] > 0)) continue;                           // stopped word
-            BowVector::iterator it = bv.lower_bound((unsigned)word[i]);
-            if (it != bv.end() && it->first == (unsigned)word[i]) { if (tf) it->second += weight[i]; }   // addWeight / addIfNotExist
-            else bv.insert(it, BowVector::value_type((unsigned)word[i], weight[i]));
-            fv[(unsigned)node[i]].push_back((unsigned)i);
+        // Both maps are built from sorted runs with end hints (linear), not by a tree search per feature.  A stable sort keeps the
+        // features of one word / node in ascending index, so a word's weights are summed in the order addWeight would see them.
+        std::vector<uint32_t> order;
+        order.reserve(word.size());
+        for (size_t i = 0; i < word.size(); ++i) if (weight[i] > 0) order.push_back((uint32_t)i);     // stopped words enter neither map
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (unsigned)word[a] < (unsigned)word[b]; });
+        for (size_t p = 0; p < order.size();) {
+            const unsigned w = (unsigned)word[order[p]];
+            double v = weight[order[p]];                              // addIfNotExist keeps the first weight, addWeight sums
+            size_t q = p + 1;
+            for (; q < order.size() && (unsigned)word[order[q]] == w; ++q) if (tf) v += weight[order[q]];
+            bv.emplace_hint(bv.end(), w, v);
+            p = q;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (unsigned)node[a] < (unsigned)node[b]; });
+        for (size_t p = 0; p < order.size();) {
+            const unsigned nd = (unsigned)node[order[p]];
+            size_t q = p;
+            while (q < order.size() && (unsigned)node[order[q]] == nd) ++q;
+            std::vector<unsigned int>& list = fv.emplace_hint(fv.end(), nd, std::vector<unsigned int>())->second;
+            list.assign(order.begin() + p, order.begin() + q);
+            std::sort(list.begin(), list.end());                       // ascending feature index (the second sort started from word order)
+            p = q;
         }
         if (tf && !bv.empty() && !must) { const double nd = (double)bv.size(); for (auto& e : bv) e.second /= nd; }
         if (must) {

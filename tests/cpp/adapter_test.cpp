@@ -2,8 +2,10 @@
 // src/Frame.cpp:3-9): make_shared<ORBextractor>(...), Extract(gray, Mat(), kps, desc),
 // MatchByBruteForce(desc1, desc2, matches).  Reads a raw 8-bit frame pair, writes results as raw
 // bytes so the python test can compare them with the oracle.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <string>
 #include "ssvio/Feature.h"
@@ -119,6 +121,25 @@ int main(int argc, char** argv)
                     if (fc->HasVocabulary()) { fprintf(stderr, "corrupt vocabulary %s accepted\n", argv[a]); return 1; }
                 }
                 printf("binary_voc=same\n");
+            }
+            if (getenv("SSVIO_ADAPTER_TIME")) {
+                // per-call cost of the unchanged C++ interfaces (pageable cv::Mat / std::vector in and out), 50 calls each after 5 warm-ups
+                auto timeit = [](const char* name, const std::function<void()>& fn) {
+                    for (int i = 0; i < 5; ++i) fn();
+                    const auto t0 = std::chrono::steady_clock::now();
+                    for (int i = 0; i < 50; ++i) fn();
+                    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 50;
+                    printf("time %-28s %8.1f us per call\n", name, us);
+                };
+                orb->keepPyramid = false;
+                std::vector<cv::KeyPoint> kt; cv::Mat dt; std::vector<cv::DMatch> mt; ssvio::Correspondences ct;
+                timeit("ORBextractor::Extract", [&] { orb->Extract(b, cv::Mat(), kt, dt); });
+                timeit("MatchByBruteForce", [&] { fm->MatchByBruteForce(db, da, mt); });
+                timeit("MatchByDBoW", [&] { fd->MatchByDBoW(db, da, mt); });
+                timeit("MatchByProject", [&] { fm->MatchByProject(p3, da, p2, db, radian, K, R, t, mt); });
+                timeit("AssembleCorrespondences", [&] { ssvio::AssembleCorrespondences(*fd, bow, ka, depA, kb, depB, cam, ct); });
+                timeit("TrackMapPoints", [&] { std::vector<cv::DMatch> l2 = m; ssvio::TrackMapPoints(*fd, l2, c.final_good_match); });
+                timeit("ManageMapPoints", [&] { ssvio::ManageMapPoints(*fd, kb, depB, cam, wt, last, observed, mnum, mpid, npt); });
             }
             printf("bow=%zu pre=%zu final=%zu track=%zu\n", bow.size(), c.pre_good_match.size(), c.final_good_match.size(), last.size());
         }
