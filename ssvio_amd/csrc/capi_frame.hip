@@ -170,7 +170,29 @@ int ssvio_track_map_points(ssvio_matcher* m, const ssvio_dmatch* last, int nlast
     SSVIO_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
     const size_t lb = align256((size_t)nlast * 16), cb = align256((size_t)ncur * 16);
-    int rc = grow(m->d_frameIn, m->frameInCap, lb + cb, s); if (rc) return rc;
+    int rc;
+    if (maxKey + 1 <= kTrackLdsTable && nlast <= 8192 && ncur <= 8192) {
+        // the per-frame case: both lists in, the new list and its count out through mapped host memory, the index map in LDS --
+        // one launch, no copy commands, one wait
+        rc = grow_mapped(m->h_fin, m->d_fin, m->finCap, lb + cb, s); if (rc) return rc;
+        rc = grow_mapped(m->h_fout, m->d_fout, m->foutCap, 16 + (size_t)nlast * 16, s); if (rc) return rc;
+        memcpy(m->h_fin, last, (size_t)nlast * 16); memcpy(m->h_fin + lb, cur, (size_t)ncur * 16);
+        *(volatile int*)m->h_fout = 0;
+        {
+            ProfScope p(m->prof, "k_track", s);
+            launch_track((const ssvio_dmatch*)m->d_fin, nlast, (const ssvio_dmatch*)(m->d_fin + lb), ncur, nullptr, maxKey + 1,
+                         (ssvio_dmatch*)(m->d_fout + 16), (int*)m->d_fout, s);
+            SSVIO_HIP(hipGetLastError());
+        }
+        SSVIO_HIP(hipStreamSynchronize(s));
+        const int got = *(const volatile int*)m->h_fout;
+        const int cnt = std::min(std::max(got, 0), nlast);
+        if (cnt > 0) memcpy(out, m->h_fout + 16, (size_t)cnt * sizeof(ssvio_dmatch));
+        *n = cnt;
+        m->prof.resolve();
+        return SSVIO_OK;
+    }
+    rc = grow(m->d_frameIn, m->frameInCap, lb + cb, s); if (rc) return rc;
     rc = grow(m->d_out, m->outCap, (size_t)nlast, s); if (rc) return rc;
     rc = grow(m->d_nout, m->noutCap, (size_t)1, s); if (rc) return rc;
     SSVIO_HIP(hipMemcpyAsync(m->d_frameIn, last, (size_t)nlast * 16, hipMemcpyHostToDevice, s));
@@ -178,7 +200,7 @@ int ssvio_track_map_points(ssvio_matcher* m, const ssvio_dmatch* last, int nlast
     rc = first_index_table(m, (const ssvio_dmatch*)(m->d_frameIn + lb), ncur, 1, maxKey + 1); if (rc) return rc;
     {
         ProfScope p(m->prof, "k_track", s);
-        launch_track((const ssvio_dmatch*)m->d_frameIn, nlast, (const ssvio_dmatch*)(m->d_frameIn + lb), m->d_table, maxKey + 1, m->d_out, m->d_nout, s);
+        launch_track((const ssvio_dmatch*)m->d_frameIn, nlast, (const ssvio_dmatch*)(m->d_frameIn + lb), ncur, m->d_table, maxKey + 1, m->d_out, m->d_nout, s);
         SSVIO_HIP(hipGetLastError());
     }
     int cnt = 0;

@@ -173,11 +173,23 @@ __global__ __launch_bounds__(256) void k_manage(const ssvio_keypoint* kps, int n
     world[3 * i] = o[0]; world[3 * i + 1] = o[1]; world[3 * i + 2] = o[2];
 }
 
-// Map::TrackMapPoints (src/Map.cpp:100-123): one workgroup, output in last_match_vec order
-__global__ __launch_bounds__(256) void k_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, const uint32_t* table,
-                                               int tableSize, ssvio_dmatch* out, int* nout)
+// Map::TrackMapPoints (src/Map.cpp:100-123): one workgroup, output in last_match_vec order.  With ldsTable the index map over
+// this_match_vec (first position per trainIdx) is built here in LDS first -- one launch for the whole call (tableSize <= kTrackLdsTable).
+__global__ __launch_bounds__(256) void k_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, int ncur, const uint32_t* table,
+                                               int tableSize, int ldsTable, ssvio_dmatch* out, int* nout)
 {
+    extern __shared__ uint32_t ltab[];
     __shared__ int wsum[4];
+    if (ldsTable) {
+        for (int k = threadIdx.x; k < tableSize; k += 256) ltab[k] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (int j = threadIdx.x; j < ncur; j += 256) {
+            const int key = cur[j].trainIdx;
+            if (key >= 0 && key < tableSize) atomicMin(&ltab[key], (uint32_t)j);
+        }
+        __syncthreads();
+        table = ltab;
+    }
     int written = 0;
     for (int i0 = 0; i0 < nlast; i0 += 256) {
         const int i = i0 + threadIdx.x;
@@ -212,10 +224,11 @@ void launch_manage(const ssvio_keypoint* kps, int nkp, const uint16_t* depth, co
                        matchNum, mapPoint, world);
 }
 
-void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, const uint32_t* table, int tableSize,
+void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, int ncur, const uint32_t* table, int tableSize,
                   ssvio_dmatch* out, int* nout, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_track, dim3(1), dim3(256), 0, s, last, nlast, cur, table, tableSize, out, nout);
+    const int ldsTable = table == nullptr;                  // no global map given: build it in LDS (the caller checked the size)
+    hipLaunchKernelGGL(k_track, dim3(1), dim3(256), ldsTable ? (size_t)tableSize * 4 : 0, s, last, nlast, cur, ncur, table, tableSize, ldsTable, out, nout);
 }
 
 }  // namespace ssvio

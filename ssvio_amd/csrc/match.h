@@ -104,8 +104,9 @@ void launch_first_index(const int32_t* rec, int n, int strideInts, int fieldOff,
 void launch_manage(const ssvio_keypoint* kps, int nkp, const uint16_t* depth, const FrameCam& c, const ManageXform& T,
                    const ssvio_dmatch* last, const uint32_t* matchTable, const int32_t* obs, const uint32_t* obsTable, int obsTableSize,
                    int32_t* matchNum, int32_t* mapPoint, float* world, hipStream_t s);
-void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, const uint32_t* table, int tableSize,
-                  ssvio_dmatch* out, int* nout, hipStream_t s);
+constexpr int kTrackLdsTable = 12288;      // index maps up to this many keys are built inside k_track (48 KB of LDS)
+void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, int ncur, const uint32_t* table /* null: built in LDS */,
+                  int tableSize, ssvio_dmatch* out, int* nout, hipStream_t s);
 
 void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);
 bool knn2_small_applies(int maxQ, int maxT, int npairs);                 // small single pairs: chunks = the waves of one workgroup, no merge launch

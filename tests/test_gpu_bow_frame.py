@@ -257,7 +257,8 @@ def test_extract_match_assemble_stays_on_the_device(mods):
     ex.close(); fm.close()
 
 
-@pytest.mark.parametrize("seed,nlast,ncur,nkp", [(1, 600, 700, 1000), (2, 1, 1, 5), (3, 300, 5, 400), (4, 1000, 1000, 300)])
+@pytest.mark.parametrize("seed,nlast,ncur,nkp", [(1, 600, 700, 1000), (2, 1, 1, 5), (3, 300, 5, 400), (4, 1000, 1000, 300),
+                                                  (5, 3000, 3000, 20000), (6, 9000, 9000, 4000)])     # beyond the in-LDS index map: global table
 def test_track_map_points_and_in_match_vec_equal_oracle(mods, seed, nlast, ncur, nkp):
     S, synth, O, V, L = mods
     rng = np.random.default_rng(seed)
