@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void k_resize2(uint8_t* __restrict__ pyr, size
     const uint8_t* S = pyr + (size_t)frame * pyrFrameBytes + offS;
     uint8_t* A = pyr + (size_t)frame * pyrFrameBytes + offA;
     uint8_t* B = pyr + (size_t)frame * pyrFrameBytes + offB;
+#pragma unroll 4
     for (int i = threadIdx.x; i < RW * RH; i += 256) {
         const int ry = i / RW, rx = i - ry * RW;
         const short4 tyA = ytA[ay0 + ry];
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(256) void k_resize2(uint8_t* __restrict__ pyr, size
         const int ox0 = firstX ? -kPadX : xtB[bx0].x, ox1 = lastX ? wA + kPadX : xtB[bx1].x;      // [ox0, ox1)
         const int oy0 = firstY ? 0 : ytB[by0].x, oy1 = lastY ? hA : ytB[by1].x;
         const int OW = ox1 - ox0, OH = oy1 - oy0;
+#pragma unroll 4
         for (int i = threadIdx.x; i < OW * OH; i += 256) {
             const int ry = i / OW, rx = i - ry * OW;
             const int x = ox0 + rx, y = oy0 + ry;
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(256) void k_resize2(uint8_t* __restrict__ pyr, size
     {   // the tile of B out of LDS
         const int px0 = firstX ? -kPadX : bx0, px1 = lastX ? wB + kPadX : bx1;
         const int PW = px1 - px0, PH = by1 - by0;
+#pragma unroll 4
         for (int i = threadIdx.x; i < PW * PH; i += 256) {
             const int ry = i / PW, rx = i - ry * PW;
             const int x = px0 + rx, y = by0 + ry;
