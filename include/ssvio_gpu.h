@@ -66,6 +66,9 @@ typedef struct ssvio_matcher ssvio_matcher;
 const char* ssvio_last_error(void);
 int  ssvio_version(void);
 int  ssvio_device_count(int* count);
+/* test hook: the next n device allocations by which a matcher handle grows its buffers fail as if HIP were out of memory
+ * (the call returns SSVIO_ERR_HIP; the handle must stay usable).  n = 0 switches it off. */
+void ssvio_test_fail_next_allocs(int n);
 
 /* ---- extractor: replaces class ORBextractor (include/Feature.h:32-103) ---- */
 /* ORBextractor::ORBextractor, src/Feature.cpp:379-444 */

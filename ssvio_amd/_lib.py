@@ -45,6 +45,7 @@ SYMBOLS = {
     "ssvio_last_error": (C.c_char_p, []),
     "ssvio_version": (_i, []),
     "ssvio_device_count": (_i, [_vp]),
+    "ssvio_test_fail_next_allocs": (None, [_i]),
     "ssvio_orb_create": (_i, [_vp, _i, _vp]),
     "ssvio_orb_destroy": (None, [_vp]),
     "ssvio_orb_get_tables": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),

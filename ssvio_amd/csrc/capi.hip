@@ -129,6 +129,15 @@ int pick_device(int device)
 }
 
 
+// test hook (ssvio_test_fail_next_allocs): the next n growing device allocations of a handle report failure
+static std::atomic<int> g_failAllocs{0};
+bool alloc_fail_injected()
+{
+    int v = g_failAllocs.load();
+    while (v > 0) if (g_failAllocs.compare_exchange_weak(v, v - 1)) return true;
+    return false;
+}
+
 int prof_out(KernelProfiler& p, const char** names, double* total_ms, int32_t* launches, int cap, int* count)
 {
     if (!count) { set_error("null count"); return SSVIO_ERR_INVALID; }
@@ -233,8 +242,8 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
         if (rc) return rc;
         SSVIO_HIP(hipStreamSynchronize(h->stream));
         orb_free_buffers(h);
-        h->geom = g;
-        fill_klevels(g, h->kl);
+        h->geom.width = h->geom.height = 0;          // committed below, once the tables are on the device: a failure in between must not
+                                                     // leave the new size with a null table pointer for the next call to trust
         // resize tables
         std::vector<int16_t> all;
         h->xTabOff.assign(g.nlevels, 0); h->yTabOff.assign(g.nlevels, 0); h->qTabOff.assign(g.nlevels, 0); h->quadOk.assign(g.nlevels, 0); h->resizeRows.assign(g.nlevels, 1);
@@ -253,6 +262,8 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
         if (all.empty()) all.resize(4);
         SSVIO_HIP(hipMalloc(&h->d_tabs, all.size() * sizeof(int16_t)));
         SSVIO_HIP(hipMemcpy(h->d_tabs, all.data(), all.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+        h->geom = g;
+        fill_klevels(g, h->kl);
     }
     if (batch > h->batchCap) {
         SSVIO_HIP(hipStreamSynchronize(h->stream));
@@ -490,7 +501,8 @@ static int orb_check(ssvio_orb* h) { if (!h) { set_error("null extractor handle"
 extern "C" {
 
 const char* ssvio_last_error(void) { return last_error_cstr(); }
-int ssvio_version(void) { return 100; }
+int ssvio_version(void) { return 200; }
+void ssvio_test_fail_next_allocs(int n) { g_failAllocs.store(n > 0 ? n : 0); }
 int ssvio_device_count(int* count)
 {
     if (!count) { set_error("null count"); return SSVIO_ERR_INVALID; }

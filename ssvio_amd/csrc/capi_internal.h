@@ -13,6 +13,8 @@ int pick_device(int device);                       // SSVIO_OK, SSVIO_ERR_NOGPU 
 int prof_out(KernelProfiler& p, const char** names, double* total_ms, int32_t* launches, int cap, int* count);   // capi.hip
 template <typename T> inline void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 template <typename T> inline void hfree(T*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } }
+// test hook: ssvio_test_fail_next_allocs(n) makes the next n growing device allocations of the handles fail (capi_match.hip)
+bool alloc_fail_injected();
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 }  // namespace ssvio
 
@@ -66,10 +68,21 @@ template <typename T> inline int grow(T*& p, size_t& cap, size_t need, hipStream
     if (need <= cap) return SSVIO_OK;
     SSVIO_HIP(hipStreamSynchronize(s));
     dfree(p);
+    cap = 0;                                  // a failed hipMalloc below must not leave the old capacity with a null block
     need += need / 4;
+    if (alloc_fail_injected()) { set_error("hipMalloc: injected failure (SSVIO_TEST_FAIL_ALLOC)"); return SSVIO_ERR_HIP; }
     SSVIO_HIP(hipMalloc(&p, need * sizeof(T)));
     cap = need;
     return SSVIO_OK;
+}
+
+// descriptor-row buffers keep their capacity in rows (32 bytes each)
+inline int grow_rows(uint8_t*& p, size_t& rows, size_t needRows, hipStream_t s)
+{
+    size_t cap = rows * 32;
+    const int rc = grow(p, cap, needRows * 32, s);
+    rows = cap / 32;                          // written back on the error path too (0 after a failed allocation)
+    return rc;
 }
 
 // (re)allocates a pinned, device-mapped host block of at least `need` bytes; waits for the stream before the old one goes
@@ -92,5 +105,11 @@ int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs);           
 // descriptor rows of a single pair on the device: small sets are packed into mapped host memory that the kernels read directly,
 // larger ones are copied into d_q / d_t (capi_match.hip)
 int stage_pair(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, const uint8_t** d_q, const uint8_t** d_t);
+// the batched matcher in two steps, shared by the allocating entry points and the one that allocates nothing (capi_match.hip)
+struct MatchPlan { int maxRows, nChunks, chunkRows, nChunksR, chunkRowsR; bool small, smallRev; size_t partialEntries, partialRevEntries; };
+int match_plan(int maxQ, int maxT, int npairs, int mode, size_t limitEntries, MatchPlan& p);
+int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
+                 const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts, const int* d_pairs, int npairs, int maxQ, int maxT, int mode,
+                 uint2* partial, uint2* partialRev, ssvio_dmatch* out, int* nout, int32_t* raw, bool profile);
 // mapped host landing area for {count, pad to 16 B, rows} of at least rowBytes (capi_match.hip)
 int ensure_result(ssvio_matcher* m, size_t rowBytes);

@@ -41,60 +41,100 @@ int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs)
     return SSVIO_OK;
 }
 
-// shared driver: descriptors on the device; pairs == nullptr means the single pair (0,0)
+// how a batch of pairs is cut into launches: chunks of the train set (forward pass; reverse pass of the cross-check) and the
+// partial-list entries (uint2) they need.  limitEntries > 0 caps the scratch (the no-allocation entry point): chunks are
+// halved until both lists fit, SSVIO_ERR_CAPACITY if one chunk per pair does not.
+int match_plan(int maxQ, int maxT, int npairs, int mode, size_t limitEntries, MatchPlan& p)
+{
+    p.maxRows = std::max(maxQ, maxT);
+    pick_chunks(maxQ, maxT, npairs, p.nChunks, p.chunkRows);
+    p.small = knn2_small_applies(maxQ, maxT, npairs); p.smallRev = false;
+    if (p.small) { p.nChunks = 1; p.chunkRows = maxT; }
+    p.nChunksR = 0; p.chunkRowsR = 0;
+    if (mode == SSVIO_MODE_CROSSCHECK) {
+        pick_chunks(maxT, maxQ, npairs, p.nChunksR, p.chunkRowsR);
+        p.smallRev = knn2_small_applies(maxT, maxQ, npairs);
+        if (p.smallRev) { p.nChunksR = 1; p.chunkRowsR = maxQ; }
+    }
+    const size_t per = (size_t)npairs * p.maxRows;
+    if (limitEntries) {
+        const size_t lim = mode == SSVIO_MODE_CROSSCHECK ? limitEntries / 2 : limitEntries;
+        if (per > lim) { set_error("%d pairs x %d rows need %zu bytes of scratch, the fixed scratch holds %zu", npairs, p.maxRows, per * 8 * (mode == SSVIO_MODE_CROSSCHECK ? 2 : 1), limitEntries * 8); return SSVIO_ERR_CAPACITY; }
+        auto fit = [&](int& nChunks, int& chunkRows, int rowsT) {
+            if ((size_t)nChunks * per <= lim) return;
+            const int want = (int)(lim / per);
+            chunkRows = ((rowsT + want - 1) / want + 127) / 128 * 128;
+            nChunks = std::max(1, (rowsT + chunkRows - 1) / chunkRows);
+        };
+        fit(p.nChunks, p.chunkRows, maxT);
+        if (mode == SSVIO_MODE_CROSSCHECK) fit(p.nChunksR, p.chunkRowsR, maxQ);
+    }
+    p.partialEntries = (size_t)p.nChunks * per; p.partialRevEntries = (size_t)p.nChunksR * per;
+    return SSVIO_OK;
+}
+
+// the launches of one batch: 2-NN per chunk (both directions for the cross-check), merge, filter.  Every buffer is the caller's.
+int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
+                 const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts, const int* d_pairs, int npairs, int maxQ, int maxT, int mode,
+                 uint2* partial, uint2* partialRev, ssvio_dmatch* out, int* nout, int32_t* raw, bool profile)
+{
+    hipStream_t s = m->stream;
+    KernelProfiler off;                                  // a disabled profiler: no events are created or recorded
+    KernelProfiler& prof = profile ? m->prof : off;
+    MatchArgs a{};
+    a.qdesc = (const uint4*)d_qdesc; a.tdesc = (const uint4*)d_tdesc;
+    a.qSetStrideRows = qStrideRows; a.tSetStrideRows = tStrideRows;
+    a.qcounts = d_qcounts; a.tcounts = d_tcounts; a.pairs = d_pairs; a.swap = 0;
+    a.nChunks = p.nChunks; a.chunkRows = p.chunkRows; a.partial = partial; a.maxRows = p.maxRows;
+    {
+        ProfScope ps(prof, "k_hamming_knn2", s);
+        if (p.small) launch_knn2_small(a, maxQ, npairs, s); else launch_knn2(a, maxQ, npairs, s);
+        SSVIO_HIP(hipGetLastError());
+    }
+    FinalizeArgs f{};
+    f.partial = partial; f.nChunks = p.nChunks; f.maxRows = p.maxRows;
+    f.qcounts = d_qcounts; f.tcounts = d_tcounts; f.pairs = d_pairs;
+    f.mode = mode; f.threshold = m->threshold; f.nnRatio = m->nnRatio;
+    f.out = out; f.nout = nout; f.raw = raw;
+    if (mode == SSVIO_MODE_CROSSCHECK) {
+        MatchArgs r = a;
+        r.qdesc = (const uint4*)d_tdesc; r.tdesc = (const uint4*)d_qdesc;
+        r.qSetStrideRows = tStrideRows; r.tSetStrideRows = qStrideRows;
+        r.qcounts = d_tcounts; r.tcounts = d_qcounts; r.swap = 1;
+        r.nChunks = p.nChunksR; r.chunkRows = p.chunkRowsR; r.partial = partialRev;
+        {
+            ProfScope ps(prof, "k_hamming_knn2", s);
+            if (p.smallRev) launch_knn2_small(r, maxT, npairs, s); else launch_knn2(r, maxT, npairs, s);
+            SSVIO_HIP(hipGetLastError());
+        }
+        f.partialRev = partialRev; f.nChunksRev = p.nChunksR;
+    }
+    {
+        ProfScope ps(prof, "k_match_finalize", s);
+        launch_finalize(f, npairs, maxQ, maxT, s);
+        SSVIO_HIP(hipGetLastError());
+    }
+    return SSVIO_OK;
+}
+
+// shared driver of the allocating entry points: descriptors on the device; pairs == nullptr means the single pair (0,0)
 static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
                      const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts,
                      const int* d_pairs, int npairs, int maxQ, int maxT, int mode,
                      ssvio_dmatch* outTo = nullptr, int* noutTo = nullptr, int32_t* rawTo = nullptr)
 {
     hipStream_t s = m->stream;
-    const int maxRows = std::max(maxQ, maxT);
-    int nChunks, chunkRows;
-    pick_chunks(maxQ, maxT, npairs, nChunks, chunkRows);
-    const bool small = knn2_small_applies(maxQ, maxT, npairs), smallRev = knn2_small_applies(maxT, maxQ, npairs);
-    if (small) { nChunks = 1; chunkRows = maxT; }
-    int rc = grow(m->d_partial, m->partialCap, (size_t)npairs * nChunks * maxRows, s); if (rc) return rc;
+    MatchPlan p;
+    int rc = match_plan(maxQ, maxT, npairs, mode, 0, p); if (rc) return rc;
+    rc = grow(m->d_partial, m->partialCap, p.partialEntries, s); if (rc) return rc;
     rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
-    if (mode == 3) { rc = grow(m->d_raw, m->rawCap, (size_t)npairs * 3 * maxRows, s); if (rc) return rc; }
-    else { rc = grow(m->d_out, m->outCap, (size_t)npairs * maxRows, s); if (rc) return rc; }
-    MatchArgs a{};
-    a.qdesc = (const uint4*)d_qdesc; a.tdesc = (const uint4*)d_tdesc;
-    a.qSetStrideRows = qStrideRows; a.tSetStrideRows = tStrideRows;
-    a.qcounts = d_qcounts; a.tcounts = d_tcounts; a.pairs = d_pairs; a.swap = 0;
-    a.nChunks = nChunks; a.chunkRows = chunkRows; a.partial = m->d_partial; a.maxRows = maxRows;
-    {
-        ProfScope p(m->prof, "k_hamming_knn2", s);
-        if (small) launch_knn2_small(a, maxQ, npairs, s); else launch_knn2(a, maxQ, npairs, s);
-        SSVIO_HIP(hipGetLastError());
-    }
-    FinalizeArgs f{};
-    f.partial = m->d_partial; f.nChunks = nChunks; f.maxRows = maxRows;
-    f.qcounts = d_qcounts; f.tcounts = d_tcounts; f.pairs = d_pairs;
-    f.mode = mode; f.threshold = m->threshold; f.nnRatio = m->nnRatio;
-    f.out = outTo ? outTo : m->d_out; f.nout = noutTo ? noutTo : m->d_nout; f.raw = rawTo ? rawTo : m->d_raw;
-    if (mode == SSVIO_MODE_CROSSCHECK) {
-        int nChunksR, chunkRowsR;
-        pick_chunks(maxT, maxQ, npairs, nChunksR, chunkRowsR);
-        if (smallRev) { nChunksR = 1; chunkRowsR = maxQ; }
-        rc = grow(m->d_partialRev, m->partialRevCap, (size_t)npairs * nChunksR * maxRows, s); if (rc) return rc;
-        MatchArgs r = a;
-        r.qdesc = (const uint4*)d_tdesc; r.tdesc = (const uint4*)d_qdesc;
-        r.qSetStrideRows = tStrideRows; r.tSetStrideRows = qStrideRows;
-        r.qcounts = d_tcounts; r.tcounts = d_qcounts; r.swap = 1;
-        r.nChunks = nChunksR; r.chunkRows = chunkRowsR; r.partial = m->d_partialRev;
-        {
-            ProfScope p(m->prof, "k_hamming_knn2", s);
-            if (smallRev) launch_knn2_small(r, maxT, npairs, s); else launch_knn2(r, maxT, npairs, s);
-            SSVIO_HIP(hipGetLastError());
-        }
-        f.partialRev = m->d_partialRev; f.nChunksRev = nChunksR;
-    }
-    {
-        ProfScope p(m->prof, "k_match_finalize", s);
-        launch_finalize(f, npairs, maxQ, maxT, s);
-        SSVIO_HIP(hipGetLastError());
-    }
-    m->lastPairs = npairs; m->lastMaxRows = maxRows;
+    if (mode == 3) { rc = grow(m->d_raw, m->rawCap, (size_t)npairs * 3 * p.maxRows, s); if (rc) return rc; }
+    else { rc = grow(m->d_out, m->outCap, (size_t)npairs * p.maxRows, s); if (rc) return rc; }
+    if (mode == SSVIO_MODE_CROSSCHECK) { rc = grow(m->d_partialRev, m->partialRevCap, p.partialRevEntries, s); if (rc) return rc; }
+    rc = match_launch(m, p, d_qdesc, qStrideRows, d_qcounts, d_tdesc, tStrideRows, d_tcounts, d_pairs, npairs, maxQ, maxT, mode,
+                      m->d_partial, m->d_partialRev, outTo ? outTo : m->d_out, noutTo ? noutTo : m->d_nout, rawTo ? rawTo : m->d_raw, true);
+    if (rc) return rc;
+    m->lastPairs = npairs; m->lastMaxRows = p.maxRows;
     return SSVIO_OK;
 }
 
@@ -118,9 +158,8 @@ int stage_pair(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const ui
         *d_q = m->d_descm; *d_t = m->d_descm + toff;
         return SSVIO_OK;
     }
-    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
-    int rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
-    rc = grow(m->d_t, tcap, (size_t)nt * 32, s); if (rc) return rc; m->tRows = tcap / 32;
+    int rc = grow_rows(m->d_q, m->qRows, (size_t)nq, s); if (rc) return rc;
+    rc = grow_rows(m->d_t, m->tRows, (size_t)nt, s); if (rc) return rc;
     rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;
     rc = upload_rows(m->d_t, t, nt, tstride, m->stageT, s); if (rc) return rc;
     *d_q = m->d_q; *d_t = m->d_t;
@@ -287,9 +326,8 @@ int ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, i
     rc = grow(m->d_keep, m->keepCap, (size_t)nq, s); if (rc) return rc;
     // every wave scans all nt projected points and many train rows: inputs are copied to HBM (reading them across the bus once per
     // wave would cost more than the copies); the match list is stored straight to mapped host memory, so the call waits once
-    size_t qcap = m->qRows * 32, tcap = m->tRows * 32;
-    rc = grow(m->d_q, qcap, (size_t)nq * 32, s); if (rc) return rc; m->qRows = qcap / 32;
-    rc = grow(m->d_t, tcap, (size_t)std::max(nt, 1) * 32, s); if (rc) return rc; m->tRows = tcap / 32;
+    rc = grow_rows(m->d_q, m->qRows, (size_t)nq, s); if (rc) return rc;
+    rc = grow_rows(m->d_t, m->tRows, (size_t)std::max(nt, 1), s); if (rc) return rc;
     rc = grow(m->d_p3d, m->p3dCap, (size_t)nq * 3, s); if (rc) return rc;
     rc = grow(m->d_p2d, m->p2dCap, (size_t)std::max(nt, 1) * 2, s); if (rc) return rc;
     rc = upload_rows(m->d_q, q, nq, qstride, m->stageQ, s); if (rc) return rc;

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int qset = a.pairs ? a.pairs[2 * pair + a.swap] : 0;
     const int tset = a.pairs ? a.pairs[2 * pair + 1 - a.swap] : 0;
-    const int nq = a.qcounts[qset], nt = a.tcounts[tset];
+    const int nq = clamp_rows(a.qcounts[qset], a.maxRows), nt = clamp_rows(a.tcounts[tset], a.maxRows);
     const int qtile = blockIdx.x * 256 * R;
     if (qtile >= nq) return;                                   // block-uniform
     const uint4* Q = a.qdesc + (size_t)qset * a.qSetStrideRows * 2;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * kSmallWaves) void k_hamming_knn2_small(MatchAr
     const int pair = blockIdx.y;
     const int qset = a.pairs ? a.pairs[2 * pair + a.swap] : 0;
     const int tset = a.pairs ? a.pairs[2 * pair + 1 - a.swap] : 0;
-    const int nq = a.qcounts[qset], nt = a.tcounts[tset];
+    const int nq = clamp_rows(a.qcounts[qset], a.maxRows), nt = clamp_rows(a.tcounts[tset], a.maxRows);
     const int q0 = blockIdx.x * 64;
     if (q0 >= nq) return;                                      // block-uniform
     const uint4* Q = a.qdesc + (size_t)qset * a.qSetStrideRows * 2;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_match_merge(uint2* partial, int nChunks
     const int pair = blockIdx.y;
     const int set = pairs ? pairs[2 * pair + side] : 0;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= counts[set]) return;
+    if (i >= clamp_rows(counts[set], maxRows)) return;
     uint2* P = partial + (size_t)pair * nChunks * maxRows;
     uint32_t k1, k2;
     merge_chunks(P, nChunks, maxRows, i, k1, k2);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int qset = a.pairs ? a.pairs[2 * pair] : 0;
     const int tset = a.pairs ? a.pairs[2 * pair + 1] : 0;
-    const int nq = a.qcounts[qset], nt = a.tcounts[tset];
+    const int nq = clamp_rows(a.qcounts[qset], a.maxRows), nt = clamp_rows(a.tcounts[tset], a.maxRows);
     const uint2* P = a.partial + (size_t)pair * a.pairStride;
     const uint2* PR = a.partialRev ? a.partialRev + (size_t)pair * a.pairStrideRev : nullptr;
     ssvio_dmatch* out = a.out ? a.out + (size_t)pair * a.maxRows : nullptr;
@@ -334,7 +334,9 @@ __global__ __launch_bounds__(256) void k_match_project(ProjectArgs a)
     if (lane == 0) {
         const int minDist = min((int)(k1 >> 23), 256), secDist = min((int)(k2 >> 23), 256);
         const bool keep = inside && minDist < a.threshold && (float)minDist < a.nnRatio * (float)secDist;   // :177-178
-        ssvio_dmatch m; m.queryIdx = i; m.trainIdx = (int)(k1 & 0x7FFFFF); m.imgIdx = -1; m.distance = (float)minDist;
+        // :166 'dist < min_dist' never fires at 256 (nor with an empty window), so best_id stays -1 there; with Threshold > 256 such a
+        // row is still emitted (:177)
+        ssvio_dmatch m; m.queryIdx = i; m.trainIdx = minDist < 256 ? (int)(k1 & 0x7FFFFF) : -1; m.imgIdx = -1; m.distance = (float)minDist;
         a.cand[i] = m; a.keep[i] = keep ? 1 : 0;
     }
 }

@@ -117,6 +117,10 @@ void launch_finalize(const FinalizeArgs& a, int npairs, int maxQ, int maxT, hipS
 #if defined(__HIPCC__)
 constexpr unsigned kKeyInit = 0xFFFFFFFFu;     // "no candidate yet" in the (dist << 23 | trainIdx) key order
 
+// rows of a set as the kernels use them: the device count clamped to what the set's slice (and the per-pair output slice)
+// can hold, so that a count above max_rows cannot push reads or writes into a neighbouring set / pair
+__device__ __forceinline__ int clamp_rows(int n, int maxRows) { return min(max(n, 0), maxRows); }
+
 // median of three unsigned values in one VALU instruction
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
 {

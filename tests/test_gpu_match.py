@@ -171,3 +171,68 @@ def test_full_size_blocks_by_properties(mods, fm):
     ok, cr = fm.MatchByCrossCheck(t, q)
     fwd = set(zip(c["queryIdx"].tolist(), c["trainIdx"].tolist())); rev = set(zip(cr["trainIdx"].tolist(), cr["queryIdx"].tolist()))
     assert fwd == rev and len(fwd) > 4000
+
+
+def test_count_above_max_rows_is_clamped_and_neighbours_stay_exact(mods):
+    """a device count above max_rows must not push reads / writes into the neighbouring set or pair slices:
+    the kernels clamp it to max_rows, the other pairs' lists stay bit-identical to the oracle"""
+    import torch
+    from ssvio_amd import _lib as L
+    S, synth, O = mods
+    nsets, stride, max_rows = 5, 640, 600
+    sets = [synth.descriptor_sets(300 + s, 8, 600)[1][:c] for s, c in enumerate([600, 431, 600, 77, 512])]
+    buf = np.zeros((nsets, stride, 32), np.uint8)
+    for s, d in enumerate(sets):
+        buf[s, :len(d)] = d
+    buf[2, 600:] = synth.descriptor_sets(999, 8, 40)[1]            # rows beyond max_rows of set 2: must never be matched
+    counts = [len(d) for d in sets]; counts[2] = 5000             # the bad count
+    pairs = np.array([[0, 1], [2, 3], [1, 2], [4, 0], [3, 4], [2, 2]], np.int32)
+    for mode, ref in ((L.MODE_BRUTEFORCE, O.match_bruteforce), (L.MODE_KNN2_RATIO, lambda a, c: O.match_knn2_ratio(a, c, 50, 0.6)),
+                      (L.MODE_CROSSCHECK, O.match_crosscheck)):
+        fm = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
+        d_desc = torch.from_numpy(buf).cuda(); d_cnt = torch.tensor(counts, dtype=torch.int32).cuda()
+        fm.match_batch_dev(d_desc, stride, max_rows, d_cnt, pairs, mode)
+        fm.sync()
+        out, n = fm.fetch_batch()
+        for p, (a, c) in enumerate(pairs):
+            want = ref(sets[a], sets[c])                          # set 2 counts as its first max_rows rows
+            assert n[p] == len(want) and np.array_equal(out[p, :n[p]].view(np.uint8), want.view(np.uint8)), (mode, p)
+        fm.close()
+
+
+def test_failed_allocation_is_reported_and_the_handle_recovers(mods):
+    """a failed hipMalloc while a handle grows must not leave the old capacity with a null block"""
+    from ssvio_amd import _lib as L
+    S, synth, O = mods
+    fm = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
+    q, t = synth.descriptor_sets(41, 5000, 5200)                   # > 4096 rows: the copied (not mapped) input path, d_q / d_t grow
+    ok, m = fm.MatchByBruteForce(q[:4200], t[:4300])
+    want = O.match_bruteforce(q[:4200], t[:4300])
+    assert np.array_equal(m.view(np.uint8), want.view(np.uint8))
+    for nfail in (1, 2, 3):
+        L.lib().ssvio_test_fail_next_allocs(nfail)
+        with pytest.raises(S.SsvioError):
+            fm.MatchByBruteForce(q, t)                             # larger than before: every buffer has to grow
+        L.lib().ssvio_test_fail_next_allocs(0)
+        ok, m = fm.MatchByBruteForce(q[:4200], t[:4300])           # fits the OLD capacity: must reallocate, not trust it
+        assert np.array_equal(m.view(np.uint8), want.view(np.uint8))
+    ok, m = fm.MatchByBruteForce(q, t)
+    assert np.array_equal(m.view(np.uint8), O.match_bruteforce(q, t).view(np.uint8))
+    fm.close()
+
+
+def test_match_by_project_empty_window_keeps_index_minus_one(mods):
+    """a reference point that projects inside the image with no train keypoint in its window keeps best_id = -1 and
+    min_dist = 256 (src/FeatureMatching.cpp:160-170); with Threshold > 256 the reference still emits it (:177)"""
+    S, synth, O = mods
+    P3, dq, p2, dt, K, R, t = _project_scene(77, 200, 300, synth)
+    fm = S.FeatureMatching(None, {"Threshold": 300, "NNRatio": 1.5})
+    ok, m = fm.MatchByProject(P3, dq, p2, dt, 0.5, K, R, t)          # a 1-px window: most points find nothing
+    want = O.match_project(P3, dq, p2, dt, 0.5, K, R, t, 300, 1.5)
+    assert np.array_equal(m.view(np.uint8), want.view(np.uint8))
+    assert (want["trainIdx"] == -1).any() and (want["trainIdx"] >= 0).any()
+    far = np.full_like(dt, 255); near = np.zeros_like(dq)            # every candidate at distance exactly 256
+    ok, m = fm.MatchByProject(P3, near, p2, far, 40.0, K, R, t)
+    want = O.match_project(P3, near, p2, far, 40.0, K, R, t, 300, 1.5)
+    assert np.array_equal(m.view(np.uint8), want.view(np.uint8)) and len(want) > 0 and (want["trainIdx"] == -1).all()
+    fm.close()
