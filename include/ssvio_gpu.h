@@ -195,6 +195,18 @@ int  ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, 
 int  ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_rows, int max_rows,
                            const int32_t* d_counts, const int32_t* pairs, int npairs, int mode,
                            const void** d_matches, const int32_t** d_nmatches);
+/* The same batched matcher for callers that cannot allocate.  No counterpart in the reference: it exists for callers under HIP
+ * graph capture, tight serving loops and harnesses that forbid hipMalloc.  The call allocates nothing (no hipMalloc / hipFree /
+ * pinned memory / events / copy commands): pair list, inputs and outputs are the caller's DEVICE memory -- d_pairs[npairs][2] int32,
+ * d_matches[npairs][max_rows] ssvio_dmatch, d_nmatches[npairs] -- and the kernels' partial 2-NN lists live in a fixed device array of
+ * SSVIO_NOALLOC_SCRATCH_BYTES per GPU (resolved once per device in ssvio_matcher_create).  Needs npairs * max_rows * 8 bytes of it
+ * (twice that for the cross-check); beyond that the call returns SSVIO_ERR_CAPACITY and launches nothing.  All calls on one GPU
+ * share the array: calls that overlap on one GPU (two handles, two streams) race -- serialise them.  Results are identical to
+ * ssvio_match_batch_dev's.  Enqueued on the handle's stream; no synchronisation; kernel profiling does not cover it. */
+#define SSVIO_NOALLOC_SCRATCH_BYTES (32u << 20)
+int  ssvio_match_batch_dev_noalloc(ssvio_matcher* m, const void* d_desc, int set_stride_rows, int max_rows,
+                                   const int32_t* d_counts, const int32_t* d_pairs, int npairs, int mode,
+                                   void* d_matches, int32_t* d_nmatches);
 /* blocks until the matcher's stream is idle */
 int  ssvio_matcher_sync(ssvio_matcher* m);
 /* copy batched results to the host: out[npairs][max_rows], n[npairs] */

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libssvio_gpu.so")
 OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_GEOMETRY, ERR_NOGPU = 0, -1, -2, -3, -4, -5
 MAX_LEVELS = 16
 MODE_BRUTEFORCE, MODE_KNN2_RATIO, MODE_CROSSCHECK = 0, 1, 2
+NOALLOC_SCRATCH_BYTES = 32 << 20
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])   # cv::KeyPoint
@@ -81,6 +82,7 @@ SYMBOLS = {
     "ssvio_match_crosscheck": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "ssvio_match_knn2_raw": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ssvio_match_batch_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "ssvio_match_batch_dev_noalloc": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "ssvio_matcher_sync": (_i, [_vp]),
     "ssvio_match_batch_fetch": (_i, [_vp, _i, _i, _vp, _vp]),
     "ssvio_vocab_create": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -15,6 +15,7 @@ template <typename T> inline void dfree(T*& p) { if (p) { (void)hipFree(p); p = 
 template <typename T> inline void hfree(T*& p) { if (p) { (void)hipHostFree(p); p = nullptr; } }
 // test hook: ssvio_test_fail_next_allocs(n) makes the next n growing device allocations of the handles fail (capi_match.hip)
 bool alloc_fail_injected();
+int noalloc_scratch_init(int device);              // capi_noalloc.hip: resolves the device address of the fixed scratch, once per device
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 }  // namespace ssvio
 

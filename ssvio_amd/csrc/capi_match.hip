@@ -237,6 +237,8 @@ int ssvio_matcher_create(int threshold, float nn_ratio, int device, ssvio_matche
         delete m; return SSVIO_ERR_HIP;
     }
     m->stream = m->own;
+    const int rs = noalloc_scratch_init(device);          // fixed scratch of ssvio_match_batch_dev_noalloc, once per device
+    if (rs) { ssvio_matcher_destroy(m); return rs; }
     *out = m;
     return SSVIO_OK;
 }

@@ -208,6 +208,11 @@ class FeatureMatching:
         self._last = (len(pairs), max_rows)
         return dm.value, dn.value
 
+    def match_batch_dev_noalloc(self, d_desc, set_stride_rows, max_rows, d_counts, d_pairs, npairs, mode, d_matches, d_nmatches):
+        """ssvio_match_batch_dev_noalloc: every pointer is the caller's device memory (torch tensors or raw addresses)"""
+        L.check(L.lib().ssvio_match_batch_dev_noalloc(self._h, L.ptr(d_desc), set_stride_rows, max_rows, L.ptr(d_counts), L.ptr(d_pairs),
+                                                      npairs, mode, L.ptr(d_matches), L.ptr(d_nmatches)))
+
     def sync(self): L.check(L.lib().ssvio_matcher_sync(self._h))
 
     def fetch_batch(self, counts_only=False):
