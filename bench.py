@@ -12,6 +12,12 @@ data-path collective); the per-rank frame counts are gathered once at the end.
 Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest share of GPU time
 in the timed region, measured with hipEvent pairs on the library's stream; `cpu_baseline` is the
 CPU oracle (oracle/, a port of the reference algorithm) timed single-threaded on a bounded sample.
+
+`value` is the DEVICE-RESIDENT rate (frames already in HBM, the contract's definition).  The same line carries, measured
+in the same process at N = 1 (`configs`): BASELINE config 1 (one frame per call, host waits), config 2 streamed (256
+distinct frames from pinned host memory, H2D copies on a copy stream inside the timed region), config 3 (1080p, 4000
+features, kNN2 ratio), a `sustained` figure over >= 1 s, and `batched_matching` (configs 4 and 5 through
+ssvio_amd.dist, the code an 8-GPU run executes).
 """
 import argparse
 import json
@@ -33,7 +39,27 @@ MATCH_CYCLES_PER_PAIR = 8 * 2.46 + 11 * 4.13
 VALU_PEAK_PAIRS = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR      # 1024 SIMDs x 2.4 GHz x 64 lanes = 2.42e12 pairs/s
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r1", "r1_final_pmc_hbm.json")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r2")
+PMC_FILE = os.path.join(PROFILE_DIR, "r2_final_pmc_hbm.json")
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: the committed rocprof / PMC figures are only carried into the line while this matches
+    the hash stored beside them (profiles/r2/r2_final_source_hash.txt, written by tools/gpu_profile.sh) -- a kernel change
+    without a fresh profile turns them into nulls instead of replaying stale numbers"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ssvio_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "ssvio_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiles_current():
+    try:
+        return open(os.path.join(PROFILE_DIR, "r2_final_source_hash.txt")).read().strip() == kernel_source_hash()
+    except OSError:
+        return False
 
 
 def pmc_traffic(kernel):
@@ -50,7 +76,7 @@ def pmc_traffic(kernel):
     return None
 
 
-STATS_FILE = os.path.join(ROOT, "profiles", "r1", "r1_final_kernel_stats.csv")
+STATS_FILE = os.path.join(PROFILE_DIR, "r2_final_kernel_stats.csv")
 
 
 def rocprof_avg_us(kernel):
@@ -66,7 +92,7 @@ def rocprof_avg_us(kernel):
     return None
 
 
-SQ_FILE = os.path.join(ROOT, "profiles", "r1", "r1_final_pmc_sq.txt")
+SQ_FILE = os.path.join(PROFILE_DIR, "r2_final_pmc_sq.txt")
 
 
 def valu_busy(kernel, kernel_us):
@@ -165,45 +191,25 @@ def cpu_baseline_all_cores(frames, nfeatures, match_mode="bf", budget_s=8.0):
             "sample": "%d frames in %.1f s, one oracle extractor per thread" % (done, dt)}
 
 
-class _DevBytes:
-    """a device buffer owned by the library, presented to torch through __cuda_array_interface__ (no copy)"""
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-
-
 def batched_matching(rank, world, dev, dist, iters=10):
-    """BASELINE configs 4 and 5: keyframe-pair blocks are dealt round-robin to the ranks, every rank
-    matches its share on its GPU, and ONE all_gather (RCCL over xGMI when world > 1) returns the best-match lists
-    (config 4) or 16-byte per-pair summaries (config 5).  Outside the frames/s timed region; reported beside it."""
+    """BASELINE configs 4 and 5 through ssvio_amd.dist -- the package code an 8-GPU run executes and that
+    tests/test_dist_gloo.py (gloo, world 2) and tests/test_gpu_dist.py (one MI355X, vs the oracle) cover: keyframe-pair blocks dealt
+    to the ranks, every rank matches its share on its GPU, and ONE all_gather (RCCL over xGMI when world > 1) returns the
+    best-match lists (config 4) or the 16-byte per-pair summaries reduced on the device (config 5).  Outside the frames/s timed
+    region; reported beside it."""
     import ssvio_amd
     from ssvio_amd import synth, dist as D, _lib as L
     fm = ssvio_amd.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6}, device=dev.index)
-    st = torch.cuda.Stream(device=dev)                            # matcher kernels, the staging copies and the collective
-    fm.set_stream(st.cuda_stream)                                 # are all ordered on this one (non-null) stream
     out = []
-    on_cpu = bool(dist) and dist.get_backend() != "nccl"          # gloo rehearsal: the gather goes through host tensors
-
-    def gather(dst, src):
-        if not dist:
-            dst[0].copy_(src)
-        elif on_cpu:
-            st.synchronize()
-            parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
-            dist.all_gather(parts, src.cpu())
-            dst.copy_(torch.stack(parts).to(dev))
-        else:
-            dist.all_gather(list(dst.unbind(0)), src)
 
     def timed(fn):
-        with torch.cuda.stream(st):
-            for _ in range(2):
-                fn()
+        for _ in range(2):
+            fn()
         torch.cuda.synchronize()
         if dist: dist.barrier()
         t0 = time.perf_counter()
-        with torch.cuda.stream(st):
-            for _ in range(iters):
-                fn()
+        for _ in range(iters):
+            fn()
         torch.cuda.synchronize()
         if dist: dist.barrier()
         dt = time.perf_counter() - t0
@@ -219,52 +225,195 @@ def batched_matching(rank, world, dev, dist, iters=10):
     d = torch.from_numpy(np.concatenate([base, q])).to(dev)             # set 0 = query frame, sets 1..64 = keyframes
     cnt = torch.full((nkf + 1,), rows, dtype=torch.int32, device=dev)
     pairs = np.array([[0, k + 1] for k in range(nkf)], np.int32)
-    mine = D.shard_pairs(nkf, rank, world)
-    per = (nkf + world - 1) // world
-    gathered = torch.empty((world, per * rows * 16 + per * 4), dtype=torch.uint8, device=dev)
-    local = torch.zeros(per * rows * 16 + per * 4, dtype=torch.uint8, device=dev)
+    blocks = D.DeviceBlocks(fm, d, rows, rows, cnt, dev)
+    work = {}
+    res = {}
 
     def cfg4():
-        if len(mine):
-            dm, dn = fm.match_batch_dev(d, rows, rows, cnt, pairs[mine], L.MODE_CROSSCHECK)
-            n = len(mine)
-            local[:n * rows * 16].copy_(torch.as_tensor(_DevBytes(dm, n * rows * 16), device=dev))
-            local[per * rows * 16:per * rows * 16 + n * 4].copy_(torch.as_tensor(_DevBytes(dn, n * 4), device=dev))
-        gather(gathered, local)
+        res["lists"], res["counts"] = D.window_matches(blocks, pairs, rank, world, L.MODE_CROSSCHECK, work=work)
 
     trace('cfg4 start')
     dt = timed(cfg4)
     trace('cfg4 done')
-    nm = gathered[:, per * rows * 16:].contiguous().view(torch.int32).cpu().numpy().reshape(world, per)
-    total = int(sum(nm[r % world, r // world] for r in range(nkf)))
-    out.append({"config": "configs[3]: 1 query x %d keyframes x %d descriptors, cross-check, pair-blocks over %d rank(s), all_gather of DMatch lists (%d KB per rank)"
-                % (nkf, rows, world, (per * rows * 16 + per * 4) // 1024),
+    total = int(res["counts"].sum().item())
+    per = (nkf + world - 1) // world
+    out.append({"config": "configs[3]: 1 query x %d keyframes x %d descriptors, cross-check, pair-blocks over %d rank(s) "
+                          "(ssvio_amd.dist.window_matches), all_gather of DMatch lists (%d KB per rank)" % (nkf, rows, world, (per * rows * 16 + per * 4) // 1024),
                 "scaling": "strong", "ms": round(dt * 1e3, 4), "descriptor_pairs_per_s": 2.0 * nkf * rows * rows / dt,
                 "query_matches_per_s": total / dt, "matches": total})
 
-    # ---- config 5 (subset): loop-candidate all-pairs, 8000 descriptors per keyframe; every rank takes 128 pair-blocks
-    # of the 276 unordered pairs of 24 keyframes (weak scaling), all_gather of 16-byte per-pair summaries
-    rows5, nset5, P = 8000, 24, 128
+    # ---- config 5 (timed subset, stated): loop-candidate all-pairs over 64 of the 4096 keyframes, 8000 descriptors each:
+    # 2016 pair-blocks of 8000 x 8000 walked in super-blocks of 8 x 8 keyframes (36 tiles dealt to the ranks), per-pair summary
+    # records reduced on the device, one all_gather.  The full set is 4160x this many pair-blocks of the same size.
+    rows5, nset5, sb5 = 8000, 64, 8
     q5, _ = synth.descriptor_sets(500, rows5 * nset5, rows5)
     d5 = torch.from_numpy(q5).to(dev)
     cnt5 = torch.full((nset5,), rows5, dtype=torch.int32, device=dev)
-    allp = D.all_pairs(nset5)
-    mine5 = (rank * 37 + np.arange(P)) % len(allp)
-    g5 = torch.empty((world, P), dtype=torch.int32, device=dev)
+    blocks5 = D.DeviceBlocks(fm, d5, rows5, rows5, cnt5, dev)
+    work5 = {}
 
     def cfg5():
-        dm, dn = fm.match_batch_dev(d5, rows5, rows5, cnt5, allp[mine5], L.MODE_BRUTEFORCE)
-        loc = torch.as_tensor(_DevBytes(dn, P * 4), device=dev).view(torch.int32)
-        gather(g5, loc)
+        res["rec"] = D.loop_candidates(blocks5, nset5, rank, world, sb=sb5, work=work5)
 
+    iters = 3
     dt5 = timed(cfg5)
     trace('cfg5 done')
-    total5 = int(g5.sum().item())
-    out.append({"config": "configs[4] subset: %d pair-blocks of %dx%d per rank (of the 276 pairs of 24 keyframes), MatchByBruteForce, all_gather of per-pair match counts"
-                % (P, rows5, rows5), "scaling": "weak", "ms": round(dt5 * 1e3, 4),
-                "descriptor_pairs_per_s": float(world) * P * rows5 * rows5 / dt5, "query_matches_per_s": total5 / dt5, "matches": total5,
-                "valu_frac": round(float(world) * P * rows5 * rows5 / dt5 / (world * VALU_PEAK_PAIRS), 4)})
+    rec = D.records_to_numpy(res["rec"])
+    npairs5 = nset5 * (nset5 - 1) // 2
+    assert rec["pair"].tolist() == list(range(npairs5))
+    total5 = int(rec["n_matches"].sum())
+    plan, load = D.deal_super_blocks(nset5, sb5, world)
+    out.append({"config": "configs[4] subset: all %d unordered pairs of %d keyframes x %d descriptors (of 4096 keyframes), MatchByBruteForce, super-blocks of "
+                          "%dx%d keyframes dealt to %d rank(s) (ssvio_amd.dist.loop_candidates), device-side {pair, n, sum_dist} records, one all_gather "
+                          "(%d KB per rank)" % (npairs5, nset5, rows5, sb5, sb5, world, max(load) * 16 // 1024),
+                "scaling": "strong", "ms": round(dt5 * 1e3, 4), "pair_blocks_per_rank": load,
+                "descriptor_pairs_per_s": float(npairs5) * rows5 * rows5 / dt5, "query_matches_per_s": total5 / dt5, "matches": total5,
+                "sum_dist": int(rec["sum_dist"].sum()),
+                "valu_frac": round(float(npairs5) * rows5 * rows5 / dt5 / (world * VALU_PEAK_PAIRS), 4),
+                "full_config_extrapolated_s": round(dt5 * (4096 * 4095 / 2) / npairs5 * world / 8, 1),
+                "full_config_note": "8 386 560 pair-blocks on 8 GPUs at this per-GPU rate"})
     fm.close()
+    return out
+
+
+class Pipeline:
+    """S handle pairs (extractor + matcher), each pair on its own HIP stream; step i runs on pair i % S"""
+
+    def __init__(self, dev, features, S, threshold=50, ratio=0.6, torch_streams=False):
+        import ssvio_amd
+        self.exs = [ssvio_amd.ORBextractor(features, 1.2, 8, 20, 7, device=dev.index) for _ in range(S)]
+        self.fms = [ssvio_amd.FeatureMatching(None, {"Threshold": threshold, "NNRatio": ratio}, device=dev.index) for _ in range(S)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if torch_streams else None
+        for i, (e, m) in enumerate(zip(self.exs, self.fms)):
+            if torch_streams:
+                e.set_stream(self.streams[i].cuda_stream)
+            m.set_stream(e.get_stream())
+        self.S, self.n = S, 0
+
+    def step(self, d_frames, B, W, H, pairs, mode, wait=False):
+        i = self.n % self.S
+        e, m = self.exs[i], self.fms[i]
+        self.n += 1
+        e.extract_batch_dev(d_frames, B, W, H, wait=wait)
+        _, d_desc, d_n, cap = e.device_results()
+        m.match_batch_dev(d_desc, cap, cap, d_n, pairs, mode)
+        if wait:
+            m.sync()
+        return i
+
+    def sync(self):
+        for e, m in zip(self.exs, self.fms):
+            m.sync(); e.sync()
+
+    def close(self):
+        for h in self.exs + self.fms:
+            h.close()
+
+
+def extra_configs(dev, frames_vga):
+    """The single-GPU BASELINE configs that are not the headline, measured in this same process (N = 1 only): every one is its own
+    timed region with a device synchronise on both sides."""
+    from ssvio_amd import synth, _lib as L
+    out = []
+    W, H = 640, 480
+
+    # ---- configs[0] on the GPU: one VGA frame per call, 500 features, BF match vs the previous frame, host waits for every call
+    p = Pipeline(dev, 500, 1)
+    d1 = torch.from_numpy(frames_vga[:16]).to(dev)
+    pairs1 = np.array([[0, 0]], np.int32)
+    for k in range(20):
+        p.step(d1[k % 16], 1, W, H, pairs1, L.MODE_BRUTEFORCE, wait=True)
+    torch.cuda.synchronize()
+    n1 = 300
+    t0 = time.perf_counter()
+    for k in range(n1):
+        p.step(d1[k % 16], 1, W, H, pairs1, L.MODE_BRUTEFORCE, wait=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kp1 = float(p.exs[0].last_counts(1)[0])
+    p.close()
+    # the same through the host-buffer entry points the unmodified Odometry loop would call (pageable numpy in and out: PCIe inclusive)
+    import ssvio_amd
+    ex = ssvio_amd.ORBextractor(500, 1.2, 8, 20, 7, device=dev.index); fm = ssvio_amd.FeatureMatching(None, {}, device=dev.index)
+    prev = ex.Extract(frames_vga[0])[1]
+    for k in range(10):
+        prev = ex.Extract(frames_vga[k % 16])[1]
+    t0 = time.perf_counter()
+    for k in range(100):
+        _, de = ex.Extract(frames_vga[k % 16])
+        fm.MatchByBruteForce(de, prev)
+        prev = de
+    dth = time.perf_counter() - t0
+    ex.close(); fm.close()
+    out.append({"config": "configs[0] on the GPU: one 640x480 frame per call, 500 features, extract + MatchByBruteForce vs the previous frame, host waits every call",
+                "value": round(n1 / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / n1 * 1e3, 4), "keypoints_per_frame": kp1,
+                "residency": "device-resident frames and results",
+                "host_buffer_api": {"value": round(100 / dth, 1), "unit": "frames/s", "ms_per_frame": round(dth / 100 * 1e3, 4),
+                                    "what": "ORBextractor.Extract + MatchByBruteForce on pageable host arrays (PCIe inclusive, python wrappers)"}})
+
+    # ---- configs[1] streamed: 256 distinct frames in pinned host memory, H2D copies on a copy stream, double-buffered against compute
+    B, S, nfr = 64, 3, 256
+    frames = synth.frame_stream(2000, nfr, H, W)
+    pinned = torch.from_numpy(frames).pin_memory()
+    p = Pipeline(dev, 1000, S, torch_streams=True)
+    copy_st = torch.cuda.Stream(device=dev)
+    nbuf = S + 1
+    d_in = [torch.empty((B, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    ready = [torch.cuda.Event() for _ in range(nbuf)]; free = [torch.cuda.Event() for _ in range(nbuf)]
+    used = [False] * nbuf
+    pairs = np.array([[f, (f - 1) % B] for f in range(B)], np.int32)
+    state = {"i": 0}
+
+    def sstep():
+        i = state["i"]; state["i"] += 1
+        b = i % nbuf; chunk = i % (nfr // B)
+        with torch.cuda.stream(copy_st):
+            if used[b]:
+                copy_st.wait_event(free[b])                       # the step that read this buffer has finished
+            d_in[b].copy_(pinned[chunk * B:(chunk + 1) * B], non_blocking=True)
+            ready[b].record(copy_st)
+        cs = p.streams[p.n % S]
+        cs.wait_event(ready[b])
+        k = p.step(d_in[b], B, W, H, pairs, L.MODE_BRUTEFORCE)
+        free[b].record(p.streams[k]); used[b] = True
+
+    for _ in range(8):
+        sstep()
+    p.sync(); torch.cuda.synchronize()
+    ns = 120
+    t0 = time.perf_counter()
+    for _ in range(ns):
+        sstep()
+    p.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kp = float(p.exs[0].last_counts(B).mean())
+    p.close()
+    out.append({"config": "configs[1] streamed: %d distinct 640x480 frames in pinned host memory, %d-frame steps, H2D on a copy stream into %d device buffers "
+                          "ahead of %d steps in flight, 1000 features, extract + MatchByBruteForce vs previous frame" % (nfr, B, nbuf, S),
+                "value": round(ns * B / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / ns * 1e3, 4), "steps": ns,
+                "residency": "PCIe feed inside the timed region", "h2d_GBps": round(ns * B * W * H / dt / 1e9, 2), "keypoints_per_frame": kp})
+
+    # ---- configs[2]: 1920x1080, 4000 features, extract + kNN2 ratio test (Threshold 50, NNRatio 0.6), 16-frame steps, 3 in flight
+    W3, H3, B3 = 1920, 1080, 16
+    f3 = synth.frame_stream(3000, B3, H3, W3)
+    d3 = torch.from_numpy(f3).to(dev)
+    p = Pipeline(dev, 4000, 3)
+    pairs3 = np.array([[f, (f - 1) % B3] for f in range(B3)], np.int32)
+    for _ in range(6):
+        p.step(d3, B3, W3, H3, pairs3, L.MODE_KNN2_RATIO)
+    p.sync(); torch.cuda.synchronize()
+    n3 = 60
+    t0 = time.perf_counter()
+    for _ in range(n3):
+        p.step(d3, B3, W3, H3, pairs3, L.MODE_KNN2_RATIO)
+    p.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kp3 = float(p.exs[0].last_counts(B3).mean())
+    _, nm3 = p.fms[(p.n - 1) % 3].fetch_batch(counts_only=True)
+    p.close()
+    out.append({"config": "configs[2]: 1920x1080, 4000 features, 8 levels, extract + kNN2 ratio test vs previous frame, %d-frame steps, 3 in flight" % B3,
+                "value": round(n3 * B3 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / n3 * 1e3, 4), "steps": n3,
+                "residency": "device-resident", "keypoints_per_frame": kp3, "matches_per_frame": round(float(nm3.mean()), 1)})
     return out
 
 
@@ -322,6 +471,7 @@ def main():
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8-f section (MatchByDBoW, correspondence assembly, cloud)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched-matching", action="store_true", help="skip the configs[3]/[4] matching section")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip configs[0], configs[1] streamed, configs[2] and the sustained run (N = 1 only anyway)")
     ap.add_argument("--sync-steps", action="store_true", help="host waits for every step (latency mode)")
     ap.add_argument("--streams", type=int, default=3, help="steps in flight: step i runs on handle pair i %% streams, each pair on its own HIP stream")
     ap.add_argument("--no-kernel-events", action="store_true", help="no hipEvent pairs inside the timed region (the roofline entry then uses "
@@ -453,6 +603,19 @@ def main():
     # per-kernel GPU time over the timed region
     times = kernel_times()
     dom_ms, dom_launches = times.get(dom, (0.0, 0))
+    # sustained: the same steps for >= 1 s of wall clock, right behind the counted ones (the counted region of a default run is a
+    # few ms: this is the figure that says the rate holds)
+    sustained = None
+    if world == 1 and not args.no_extra_configs:
+        profiling(False)
+        nsus = max(args.steps, int(1.2 / max(dt / args.steps, 1e-6)) + 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nsus):
+            step()
+        sync_all(); torch.cuda.synchronize()
+        dts = time.perf_counter() - t1
+        sustained = {"value": round(B * nsus / dts, 2), "unit": "frames/s", "steps": nsus, "seconds": round(dts, 3)}
     # the same steps again, one in flight, with event pairs around every kernel: the per-kernel table (exclusive times)
     profiling(False); profiling(True)
     inflight[0] = 1
@@ -473,17 +636,19 @@ def main():
                       "alg_bytes_per_launch": int(ab), "GBps": round(ab / (avg_us * 1e-6) / 1e9, 1) if avg_us > 0 else None}
     if dom_launches == 0:                      # --no-kernel-events: the exclusive pass is the only measurement
         dom_ms, dom_launches = times[dom]
+    prof_ok = profiles_current() and (B, W, H, args.features) == (64, 640, 480, 1000)
     dom_avg_s = dom_ms * 1e-3 / dom_launches
     dom_bytes = algorithmic_bytes(dom, B, px, int(counts.sum()), pairs_rows)
     achieved = dom_bytes / dom_avg_s / 1e9
     roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom) if (B, W, H, args.features) == (64, 640, 480, 1000) else None,
-            "traffic_source": "profiles/r1/r1_final_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, default batch)",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom) if prof_ok else None,
+            "traffic_source": "profiles/r2/r2_final_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, default batch); null when the "
+                              "kernel sources have changed since that profile (profiles/r2/r2_final_source_hash.txt)",
             "avg_launch_us": round(dom_avg_s * 1e6, 2), "alg_bytes_per_launch": int(dom_bytes),
             "avg_launch_note": "hipEvent pair around the kernel on its stream inside the timed region: with several steps in flight it includes "
                                "the wait for CUs held by the other steps' kernels; exclusive_* is the same kernel with one step in flight",
-            "rocprof_avg_launch_us": rocprof_avg_us(dom) if (B, W, H, args.features) == (64, 640, 480, 1000) else None,
-            "valu_busy": valu_busy(dom, times[dom][0] * 1e3 / times[dom][1]) if (B, W, H, args.features) == (64, 640, 480, 1000) else None,
+            "rocprof_avg_launch_us": rocprof_avg_us(dom) if prof_ok else None,
+            "valu_busy": valu_busy(dom, times[dom][0] * 1e3 / times[dom][1]) if prof_ok else None,
             "binds": "VALU issue, not HBM: the path is integer byte work with ~60 lane-instructions per pixel (DESIGN.md section 3); the HBM fraction is reported because the contract asks for it",
             "exclusive_avg_launch_us": round(times[dom][0] * 1e3 / times[dom][1], 2),
             "exclusive_frac": round(dom_bytes / (times[dom][0] * 1e-3 / times[dom][1]) / 1e9 / HBM_PEAK_GBS, 5)}
@@ -501,9 +666,12 @@ def main():
     trace('kernel table done')
     nxt = None if (args.no_next_rows or rank != 0) else next_rows(exs[0], fms[0], d_frames, B, W, H, pairs, dev)   # no collective inside: rank 0 only
     bm = None if args.no_batched_matching else batched_matching(rank, world, dev, dist)
+    xc = extra_configs(dev, frames) if (world == 1 and not args.no_extra_configs and (W, H) == (640, 480)) else None
     if rank == 0:
         out = {
-            "metric": "ORB extract + BF-match frames/s @VGA (BASELINE config 2)",
+            "metric": "ORB extract + match frames/s (%s)" % ("BASELINE configs[1], VGA, device-resident" if (W, H, args.features, args.match_mode) == (640, 480, 1000, "bf")
+                                                             else "BASELINE configs[2], 1080p, device-resident" if (W, H, args.features, args.match_mode) == (1920, 1080, 4000, "ratio")
+                                                             else "non-BASELINE workload, see config.workload"),
             "value": round(total_frames / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -512,7 +680,9 @@ def main():
                                    % ("configs[1]" if (W, H, args.features, args.match_mode) == (640, 480, 1000, "bf") else "configs[2]" if (W, H, args.features, args.match_mode) == (1920, 1080, 4000, "ratio") else "custom",
                                       W, H, args.features, {"bf": "MatchByBruteForce", "ratio": "kNN2 ratio test", "crosscheck": "cross-check", "dbow": "MatchByDBoW (synthetic k=10 L=6 vocabulary)"}[args.match_mode]),
                        "frames_per_step": B, "parallelism": "frames sharded over %d rank(s), replicas, no collective on the data path" % world,
-                       "steps_in_flight": S},
+                       "steps_in_flight": S, "residency": "device-resident: the %d frames of a step are in HBM before the timed region (configs[].residency for the streamed run)" % B},
+            "sustained": sustained,
+            "configs": xc,
             "keypoints_per_frame": round(float(counts.mean()), 1),
             "matches_per_frame": round(float(nmatch.mean()), 1),
             "query_matches_per_s": round(float(nmatch.sum()) * args.steps * world / dt, 1),

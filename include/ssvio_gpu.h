@@ -195,6 +195,16 @@ int  ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, 
 int  ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_rows, int max_rows,
                            const int32_t* d_counts, const int32_t* pairs, int npairs, int mode,
                            const void** d_matches, const int32_t** d_nmatches);
+/* Loop-candidate matching (BASELINE config 5) keeps only a fixed-size summary per keyframe pair: the reference has
+ * no consumer for it (src/Loop.cpp:1 is empty), each record is what MatchByBruteForce's `matches` (src/FeatureMatching.cpp:47-54)
+ * reduces to.  rec[k] for pair k of the LAST ssvio_match_batch_dev / ssvio_match_dbow_batch_dev call on this handle, reduced on the
+ * device into d_records[npairs] (caller's device memory, 16-byte records); enqueued on the stream, no synchronisation.
+ * id_mode SSVIO_PAIR_ID_SEQUENTIAL: pair = id_base + k; SSVIO_PAIR_ID_TRIANGULAR: pair = hi*(hi-1)/2 + lo of the pair's two set
+ * indices (the numbering of unordered pairs). */
+typedef struct ssvio_pair_summary { int32_t pair; int32_t n_matches; int64_t sum_dist; } ssvio_pair_summary;
+#define SSVIO_PAIR_ID_SEQUENTIAL 0
+#define SSVIO_PAIR_ID_TRIANGULAR 1
+int  ssvio_match_batch_summary_dev(ssvio_matcher* m, int id_mode, int id_base, void* d_records);
 /* The same batched matcher for callers that cannot allocate.  No counterpart in the reference: it exists for callers under HIP
  * graph capture, tight serving loops and harnesses that forbid hipMalloc.  The call allocates nothing (no hipMalloc / hipFree /
  * pinned memory / events / copy commands): pair list, inputs and outputs are the caller's DEVICE memory -- d_pairs[npairs][2] int32,

@@ -14,6 +14,8 @@ OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_GEOMETRY, ERR_NOGPU = 0, -1, -2, -3,
 MAX_LEVELS = 16
 MODE_BRUTEFORCE, MODE_KNN2_RATIO, MODE_CROSSCHECK = 0, 1, 2
 NOALLOC_SCRATCH_BYTES = 32 << 20
+PAIR_ID_SEQUENTIAL, PAIR_ID_TRIANGULAR = 0, 1
+REC_DTYPE = np.dtype([("pair", "<i4"), ("n_matches", "<i4"), ("sum_dist", "<i8")])   # ssvio_pair_summary
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])   # cv::KeyPoint
@@ -82,6 +84,7 @@ SYMBOLS = {
     "ssvio_match_crosscheck": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "ssvio_match_knn2_raw": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ssvio_match_batch_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "ssvio_match_batch_summary_dev": (_i, [_vp, _i, _i, _vp]),
     "ssvio_match_batch_dev_noalloc": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "ssvio_matcher_sync": (_i, [_vp]),
     "ssvio_match_batch_fetch": (_i, [_vp, _i, _i, _vp, _vp]),

@@ -284,7 +284,7 @@ int ssvio_match_dbow_batch_dev(ssvio_matcher* m, const ssvio_vocab* v, const voi
         launch_match_grouped(g, max_rows, npairs, s);
         SSVIO_HIP(hipGetLastError());
     }
-    m->lastPairs = npairs; m->lastMaxRows = max_rows;
+    m->lastPairs = npairs; m->lastMaxRows = max_rows; m->lastHadPairs = true;
     m->lastBowQ = 0; m->lastBowT = 0;
     if (d_matches) *d_matches = m->d_out;
     if (d_nmatches) *d_nmatches = m->d_nout;

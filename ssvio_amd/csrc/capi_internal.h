@@ -60,7 +60,7 @@ struct ssvio_matcher {
     std::vector<uint8_t> stageQ, stageT;              // packed copies of strided descriptor rows
     std::vector<int32_t> h_pairs;                     // what d_pairs holds (an unchanged pair list is not uploaded again)
     KernelProfiler prof; std::string profOnly;
-    int lastPairs = 0, lastMaxRows = 0;
+    int lastPairs = 0, lastMaxRows = 0; bool lastHadPairs = false;    // the last batched call: d_out / d_nout hold lastPairs lists; d_pairs is its pair list
 };
 
 // grows a device array of the handle (never shrinks); waits for the stream first: queued work may still use the old block

@@ -134,7 +134,7 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
     rc = match_launch(m, p, d_qdesc, qStrideRows, d_qcounts, d_tdesc, tStrideRows, d_tcounts, d_pairs, npairs, maxQ, maxT, mode,
                       m->d_partial, m->d_partialRev, outTo ? outTo : m->d_out, noutTo ? noutTo : m->d_nout, rawTo ? rawTo : m->d_raw, true);
     if (rc) return rc;
-    m->lastPairs = npairs; m->lastMaxRows = p.maxRows;
+    m->lastPairs = npairs; m->lastMaxRows = p.maxRows; m->lastHadPairs = false;
     return SSVIO_OK;
 }
 
@@ -376,8 +376,23 @@ int ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_r
     rc = match_run(m, (const uint8_t*)d_desc, set_stride_rows, d_counts, (const uint8_t*)d_desc, set_stride_rows, d_counts,
                    m->d_pairs, npairs, max_rows, max_rows, mode);
     if (rc) return rc;
+    m->lastHadPairs = true;
     if (d_matches) *d_matches = m->d_out;
     if (d_nmatches) *d_nmatches = m->d_nout;
+    return SSVIO_OK;
+}
+
+int ssvio_match_batch_summary_dev(ssvio_matcher* m, int id_mode, int id_base, void* d_records)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (!d_records || (id_mode != SSVIO_PAIR_ID_SEQUENTIAL && id_mode != SSVIO_PAIR_ID_TRIANGULAR)) { set_error("bad summary arguments"); return SSVIO_ERR_INVALID; }
+    if (m->lastPairs <= 0 || !m->d_out || !m->d_nout || !m->lastHadPairs) {
+        set_error("no batched result with a pair list to summarise"); return SSVIO_ERR_INVALID;
+    }
+    SSVIO_HIP(hipSetDevice(m->device));
+    ProfScope p(m->prof, "k_pair_summary", m->stream);
+    launch_pair_summary(m->d_out, m->d_nout, m->lastMaxRows, m->d_pairs, m->lastPairs, id_mode, id_base, (ssvio_pair_summary*)d_records, m->stream);
+    SSVIO_HIP(hipGetLastError());
     return SSVIO_OK;
 }
 

@@ -363,6 +363,39 @@ void launch_project(const ProjectArgs& a, hipStream_t s)
     hipLaunchKernelGGL(k_project_compact, dim3(1), dim3(256), 0, s, a);
 }
 
+// per-pair summary record {pair id, number of matches, sum of their distances}: one wave per pair walks the pair's DMatch
+// list (distances are integers 0..256 held in floats, so the integer sum is exact)
+__global__ __launch_bounds__(256) void k_pair_summary(const ssvio_dmatch* __restrict__ out, const int* __restrict__ nout, int maxRows,
+                                                      const int* __restrict__ pairs, int npairs, int idMode, int idBase,
+                                                      ssvio_pair_summary* __restrict__ rec)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= npairs) return;                                   // wave-uniform
+    const int n = clamp_rows(nout[p], maxRows);
+    const ssvio_dmatch* M = out + (size_t)p * maxRows;
+    long long sum = 0;
+    for (int i = lane; i < n; i += 64) sum += (long long)(int)M[i].distance;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) {
+        int id = idBase + p;
+        if (idMode == SSVIO_PAIR_ID_TRIANGULAR) {
+            const int a = pairs[2 * p], b = pairs[2 * p + 1];
+            const long long hi = max(a, b), lo = min(a, b);
+            id = (int)(hi * (hi - 1) / 2 + lo);
+        }
+        ssvio_pair_summary r; r.pair = id; r.n_matches = n; r.sum_dist = sum;
+        rec[p] = r;
+    }
+}
+
+void launch_pair_summary(const ssvio_dmatch* out, const int* nout, int maxRows, const int* pairs, int npairs, int idMode, int idBase,
+                         ssvio_pair_summary* rec, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pair_summary, dim3((npairs + 3) / 4), dim3(256), 0, s, out, nout, maxRows, pairs, npairs, idMode, idBase, rec);
+}
+
 void launch_finalize(const FinalizeArgs& a0, int npairs, int maxQ, int maxT, hipStream_t s)
 {
     FinalizeArgs a = a0;

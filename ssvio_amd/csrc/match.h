@@ -108,6 +108,8 @@ constexpr int kTrackLdsTable = 12288;      // index maps up to this many keys ar
 void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, int ncur, const uint32_t* table /* null: built in LDS */,
                   int tableSize, ssvio_dmatch* out, int* nout, hipStream_t s);
 
+void launch_pair_summary(const ssvio_dmatch* out, const int* nout, int maxRows, const int* pairs, int npairs, int idMode, int idBase,
+                         ssvio_pair_summary* rec, hipStream_t s);
 void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);
 bool knn2_small_applies(int maxQ, int maxT, int npairs);                 // small single pairs: chunks = the waves of one workgroup, no merge launch
 void launch_knn2_small(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);   // writes partial[pair][q] (nChunks = 1, pair stride maxRows)

@@ -208,6 +208,10 @@ class FeatureMatching:
         self._last = (len(pairs), max_rows)
         return dm.value, dn.value
 
+    def batch_summary_dev(self, d_records, id_mode=L.PAIR_ID_SEQUENTIAL, id_base=0):
+        """16-byte {pair, n_matches, sum_dist} records of the last batched call, reduced on the device into d_records"""
+        L.check(L.lib().ssvio_match_batch_summary_dev(self._h, id_mode, id_base, L.ptr(d_records)))
+
     def match_batch_dev_noalloc(self, d_desc, set_stride_rows, max_rows, d_counts, d_pairs, npairs, mode, d_matches, d_nmatches):
         """ssvio_match_batch_dev_noalloc: every pointer is the caller's device memory (torch tensors or raw addresses)"""
         L.check(L.lib().ssvio_match_batch_dev_noalloc(self._h, L.ptr(d_desc), set_stride_rows, max_rows, L.ptr(d_counts), L.ptr(d_pairs),

@@ -5,7 +5,7 @@
 # Results land in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 tag=${1:-prof}; R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-BENCH="$R/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+BENCH="$R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs --no-batched-matching --no-next-rows"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -- python3 $BENCH > $R/gpurun_out/${tag}_trace.log 2>&1 || { tail -5 $R/gpurun_out/${tag}_trace.log; exit 1; }
 grep '"metric"' $R/gpurun_out/${tag}_trace.log > $R/gpurun_out/${tag}_bench_under_trace.json
 cp $(ls $R/gpurun_out/${tag}_trace/*/*kernel_stats.csv | tail -1) $R/gpurun_out/${tag}_kernel_stats.csv && head -14 $R/gpurun_out/${tag}_kernel_stats.csv
@@ -26,6 +26,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         kb = sum(v) / len(v)
         out[k][c] = {"launches": len(v), "avg_KB_raw": kb, "avg_bytes_corrected": kb * 1024 * (2 if c == "FETCH_SIZE" else 1)}
 json.dump(out, open("$R/gpurun_out/${tag}_pmc_hbm.json", "w"), indent=1)
+import sys
+sys.path.insert(0, "$R")
+import bench
+open("$R/gpurun_out/${tag}_source_hash.txt", "w").write(bench.kernel_source_hash() + "\n")
 for k, v in out.items():
     print("%-40s fetch %10.0f KB (x2 corrected)  write %10.0f KB" % (k[:40], v.get("FETCH_SIZE", {}).get("avg_bytes_corrected", 0) / 1024, v.get("WRITE_SIZE", {}).get("avg_bytes_corrected", 0) / 1024))
 PY
