@@ -37,7 +37,9 @@ public:
         status_ = SSVIO_OK;
         cv::Mat img = image.getMat();
         if (img.empty()) return;                                   // :507-508 silent return
-        if (img.type() != CV_8UC1) throw std::invalid_argument("ORBextractor::Extract: image.type() == CV_8UC1");   // assert, :511
+        // assert(image.type() == CV_8UC1), :511 (active in the reference's Release build: it aborts).  The adapter does not throw
+        // across the reference's exception-free interface: outputs empty, lastStatus() = SSVIO_ERR_INVALID.
+        if (img.type() != CV_8UC1) { status_ = SSVIO_ERR_INVALID; keypoints.clear(); descriptors.release(); return; }
         const int cap = ssvio_orb_max_keypoints(h_);
         kp_.resize(cap); desc_.resize((size_t)cap * 32);
         int n = 0;

@@ -168,6 +168,12 @@ int  ssvio_match_knn2_ratio(ssvio_matcher* m, const uint8_t* q, int nq, int qstr
 /* BFMatcher(NORM_HAMMING, crossCheck=true) as mutual nearest neighbours (no reference code) */
 int  ssvio_match_crosscheck(ssvio_matcher* m, const uint8_t* q, int nq, int qstride,
                             const uint8_t* t, int nt, int tstride, ssvio_dmatch* out, int cap, int* n);
+/* BFMatcher(NORM_HAMMING, crossCheck=true) the way OpenCV 3.x itself computes it ("OpenCV-compat"; recalled, not
+ * verifiable here): only the reverse search is run -- every train row votes for its nearest query row (lowest query index on
+ * ties), a query keeps the closest train among its voters (lowest train index on ties) and is emitted iff it got a vote.  This
+ * differs from the mutual nearest neighbour above when a query's own nearest train prefers another query.  imgIdx = 0. */
+int  ssvio_match_crosscheck_cv(ssvio_matcher* m, const uint8_t* q, int nq, int qstride,
+                               const uint8_t* t, int nt, int tstride, ssvio_dmatch* out, int cap, int* n);
 /* raw 2-NN of src/FeatureMatching.cpp:85-102 / ComputeMatchingScore :211-228:
  * idx[i] (-1 if best distance is 256), d1[i], d2[i] */
 int  ssvio_match_knn2_raw(ssvio_matcher* m, const uint8_t* q, int nq, int qstride,
@@ -186,12 +192,13 @@ int  ssvio_match_project(ssvio_matcher* m, const double* p3d, const uint8_t* q, 
 /* Batched matching over descriptor sets resident in HBM (BASELINE configs 2, 4, 5).
  * d_desc: set s occupies rows [s*set_stride_rows, +counts[s]) of a contiguous [rows][32] byte array.
  * d_counts: int32 per set (device).  pairs: host array of npairs (query_set, train_set) int32 pairs.
- * mode: 0 = bruteforce filter, 1 = knn2+ratio, 2 = crosscheck.
+ * mode: 0 = bruteforce filter, 1 = knn2+ratio, 2 = crosscheck (mutual NN), 4 = crosscheck as OpenCV computes it.
  * Output (device, owned by the handle until the next call): d_matches[npairs][max_rows] ssvio_dmatch
  * and d_nmatches[npairs].  Enqueued on the stream; no synchronisation. */
 #define SSVIO_MODE_BRUTEFORCE 0
 #define SSVIO_MODE_KNN2_RATIO 1
 #define SSVIO_MODE_CROSSCHECK 2
+#define SSVIO_MODE_CROSSCHECK_CV 4  /* the OpenCV-compat cross-check of ssvio_match_crosscheck_cv (3 is internal) */
 int  ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_rows, int max_rows,
                            const int32_t* d_counts, const int32_t* pairs, int npairs, int mode,
                            const void** d_matches, const int32_t** d_nmatches);
@@ -320,9 +327,33 @@ int  ssvio_manage_map_points(ssvio_matcher* m, const ssvio_keypoint* kps, int nk
  * pcl::PointXYZRGB (32 bytes: x, y, z, 1.0f, b, g, r, a = 255, 12 bytes of padding written as 0) per pixel, point index
  * u * h + v for pixel (x = u, y = v).  depth: 16U w x h; bgr: 8UC3 with bytes B, G, R (:215).  depth_scale is the driver's
  * DOUBLE _DepthScale (driver/Xtion_Driver.h:47: (float)yaml DepthScale / 65535.0), cam->depth_scale is not used.
- * out: w*h records.  (The voxel-grid fusion of Map::MapPointCloudFusion is PCL code and is not built.) */
+ * out: w*h records. */
 int  ssvio_rgb_cloud(ssvio_matcher* m, const uint16_t* depth, int depth_stride_px, const uint8_t* bgr, int bgr_stride,
                      int w, int h, const ssvio_camera* cam, double depth_scale, void* out);
+
+/* ---- point-cloud map (second half) ------------------------------------------------------- */
+/* Map::MapPointCloudFusion, src/Map.cpp:164-197.  The map (_final_cloud) lives in HBM inside the matcher handle; every
+ * ssvio_map_fuse* call is ONE iteration of the reference's key-frame loop (:166-192):
+ *   the frame's cloud is transformed with Eigen::Affine3f::Identity().rotate(R).translate(t), R / t the rotation / translation
+ *   blocks of this_trans = GetAbsPose().inverse() (:174-181) -- as written that is p' = R*p + R*t --, appended to the map (:183),
+ *   and the whole is filtered by pcl::VoxelGrid with leaf voxel_size (= _VoxelSize, config/default_conf.yaml:23) on all axes
+ *   (:185-190); the filtered cloud is the new map (:192).
+ * PCL (transformPointCloud, VoxelGrid::applyFilter with CentroidPoint, version 1.8 / 1.9) is restated from PCL's published source
+ * (DESIGN.md); parity unpinned (PCL is absent from this image).  One canonical choice: PCL sorts a voxel's points with the unstable std::sort
+ * before it sums them; here they are summed in their order in the concatenated cloud (map points first, then the frame's).
+ * Output order: ascending voxel index, as PCL.  Points are 32-byte pcl::PointXYZRGB records (ssvio_rgb_cloud's layout); outputs
+ * carry data[3] = 1 and zeroed padding.  this_trans: 16 floats in Eigen::Matrix4f::data() order (column-major).  Non-finite
+ * coordinates are refused (the reference's clouds are dense).  When the voxel grid would overflow 32-bit indices PCL returns its
+ * input unchanged; so does this.  Each call waits for its result (the new map size sizes the next call). */
+int  ssvio_map_set(ssvio_matcher* m, const void* points, int n);                 /* load a map from the host; n = 0 clears it */
+int  ssvio_map_fuse(ssvio_matcher* m, const void* cloud, int n, const float* this_trans, float voxel_size);       /* host cloud */
+int  ssvio_map_fuse_dev(ssvio_matcher* m, const void* d_cloud, int n, const float* this_trans, float voxel_size); /* device cloud */
+/* the frame's cloud is built on the device from its depth and BGR images exactly as ssvio_rgb_cloud does, then fused */
+int  ssvio_map_fuse_frame(ssvio_matcher* m, const uint16_t* depth, int depth_stride_px, const uint8_t* bgr, int bgr_stride, int w, int h,
+                          const ssvio_camera* cam, double depth_scale, const float* this_trans, float voxel_size);
+/* *n = points in the map; out (may be NULL) receives them when cap >= *n */
+int  ssvio_map_fetch(ssvio_matcher* m, void* out, int cap, int* n);
+int  ssvio_map_device(ssvio_matcher* m, const void** d_points, int* n);
 
 #ifdef __cplusplus
 }

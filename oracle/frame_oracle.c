@@ -9,11 +9,15 @@
  *   src/Map.cpp:125-149         Map::ManageMapPoints (decisions + values) with Frame::GetMapPointID, src/Frame.cpp:138-147
  *                                                                      -> orc_manage_map_points
  *   driver/Xtion_Driver.cpp:138-162, :219-229  XtionCamera::GetRGB3DPoint over the frame -> orc_rgb_cloud (f4, first half)
+ *   src/Map.cpp:164-197         Map::MapPointCloudFusion, one key frame -> orc_voxel_fuse (f4, second half; PCL restated)
  *   All float arithmetic is single precision, evaluated left to right, no contraction.
  */
 #include "ssvio_oracle.h"
 #include <float.h>
+#include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
 
 /* cam: InnerCx, InnerCy, InnerFx, InnerFy, DepthScale (= yaml DepthScale / 65535.0 narrowed to float, include/Init.h:14-20) */
 void orc_get_3d_point(const orc_keypoint* kps, int index, const uint16_t* depth, int depth_stride_px,
@@ -148,4 +152,98 @@ void orc_rgb_cloud(const uint16_t* depth, int depth_stride_px, const uint8_t* bg
             for (int k = 20; k < 32; ++k) o[k] = 0;
         }
     }
+}
+
+/* ---- Map::MapPointCloudFusion, src/Map.cpp:164-197 (second half): ONE iteration of its key-frame loop.
+ *
+ * PARITY UNPINNED: the arithmetic lives in PCL (pcl::transformPointCloud, pcl::VoxelGrid<PointXYZRGB>, un-vendored, not in
+ * this image; CMakeLists.txt:31 `find_package(PCL REQUIRED)` pins no version) and in Eigen (Affine3f).  Restated from the
+ * published PCL 1.8/1.9 sources:
+ *   transform (src/Map.cpp:175-181): Affine3f::Identity().rotate(R).translate(t) has linear part R and translation R*t, i.e.
+ *     p' = R*p + R*t (NOT R*p + t).  R*t row r in Eigen's fixed-size order R(r,0)*t0 + (R(r,1)*t1 + R(r,2)*t2);
+ *     transformPointCloud (dense cloud): x' = ((m00*x + m01*y) + m02*z) + m03, all float, colour and data[3] copied.
+ *   concatenation (:183): the transformed points follow the points already in the map.
+ *   VoxelGrid::applyFilter (:185-190), leaf = _VoxelSize on all axes, downsample_all_data = true, min_points_per_voxel = 0:
+ *     inverse_leaf = 1.f / leaf; getMinMax3D over all points; d{x,y,z} = (int64)((max - min) * inverse_leaf) + 1 and, when
+ *     dx*dy*dz > INT32_MAX, the filter warns and returns the input unchanged; min_b = (int)floor(min * inverse_leaf),
+ *     div_b = max_b - min_b + 1; ijk = (int)(floor(p * inverse_leaf) - (float)min_b); idx = i + j*div_x + k*div_x*div_y;
+ *     sort by idx; one output point per run of equal idx, in ascending idx: CentroidPoint -- xyz = (sum of xyz) / (float)n,
+ *     rgba = (uint32)(sum a / n) << 24 | (uint32)(sum r / n) << 16 | (uint32)(sum g / n) << 8 | (uint32)(sum b / n) with float
+ *     sums; data[3] = 1 (PointXYZRGB's constructor).
+ * Where PCL is not a function of its inputs: std::sort is unstable, so the order in which a voxel's points are summed (and
+ * with it the last bits of the float sums) depends on the library build.  Canonical here, as for the quadtree:
+ * stable by position in the concatenated cloud.
+ * this_trans: 16 floats, Eigen::Matrix4f::data() order (column-major) of GetAbsPose().inverse() (:174).
+ * points: 32-byte records {x, y, z, data[3], b, g, r, a, 12 bytes}.  Returns the number of output points (<= cap assumed). */
+typedef struct { uint32_t idx; uint32_t pos; } orc_vox_key;
+
+static int orc_vox_cmp(const void* a, const void* b)
+{
+    const orc_vox_key* x = (const orc_vox_key*)a; const orc_vox_key* y = (const orc_vox_key*)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos ? 1 : 0);
+}
+
+int orc_voxel_fuse(const uint8_t* final_cloud, int n_final, const uint8_t* frame_cloud, int n_frame,
+                   const float* this_trans, float voxel_size, uint8_t* out)
+{
+    const int n = n_final + n_frame;
+    if (n <= 0) return 0;
+    uint8_t* all = (uint8_t*)malloc((size_t)n * 32);
+    memcpy(all, final_cloud, (size_t)n_final * 32);
+    /* :175-181 */
+    float m[3][4];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) m[r][c] = this_trans[c * 4 + r];
+        const float t0 = this_trans[12], t1 = this_trans[13], t2 = this_trans[14];
+        m[r][3] = m[r][0] * t0 + (m[r][1] * t1 + m[r][2] * t2);
+    }
+    for (int i = 0; i < n_frame; ++i) {
+        const uint8_t* s = frame_cloud + (size_t)i * 32; uint8_t* d = all + (size_t)(n_final + i) * 32;
+        float p[3]; memcpy(p, s, 12);
+        float q[3];
+        for (int r = 0; r < 3; ++r) q[r] = ((m[r][0] * p[0] + m[r][1] * p[1]) + m[r][2] * p[2]) + m[r][3];
+        memcpy(d, s, 32); memcpy(d, q, 12);
+    }
+    /* getMinMax3D */
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = 0; i < n; ++i) {
+        float p[3]; memcpy(p, all + (size_t)i * 32, 12);
+        for (int k = 0; k < 3; ++k) { if (p[k] < mn[k]) mn[k] = p[k]; if (p[k] > mx[k]) mx[k] = p[k]; }
+    }
+    const float inv = 1.0f / voxel_size;
+    const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)INT32_MAX) {          /* "Leaf size is too small for the input dataset": output = input */
+        memcpy(out, all, (size_t)n * 32); free(all); return n;
+    }
+    int minb[3], divb[3];
+    for (int k = 0; k < 3; ++k) { minb[k] = (int)floorf(mn[k] * inv); divb[k] = (int)floorf(mx[k] * inv) - minb[k] + 1; }
+    orc_vox_key* keys = (orc_vox_key*)malloc((size_t)n * sizeof(orc_vox_key));
+    for (int i = 0; i < n; ++i) {
+        float p[3]; memcpy(p, all + (size_t)i * 32, 12);
+        const int i0 = (int)(floorf(p[0] * inv) - (float)minb[0]), i1 = (int)(floorf(p[1] * inv) - (float)minb[1]), i2 = (int)(floorf(p[2] * inv) - (float)minb[2]);
+        keys[i].idx = (uint32_t)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]); keys[i].pos = (uint32_t)i;
+    }
+    qsort(keys, (size_t)n, sizeof(orc_vox_key), orc_vox_cmp);
+    int total = 0;
+    for (int a = 0; a < n;) {
+        int b = a + 1;
+        while (b < n && keys[b].idx == keys[a].idx) ++b;
+        float sx = 0, sy = 0, sz = 0, sr = 0, sg = 0, sb = 0, sa = 0;
+        for (int j = a; j < b; ++j) {
+            const uint8_t* s = all + (size_t)keys[j].pos * 32;
+            float p[3]; memcpy(p, s, 12);
+            sx += p[0]; sy += p[1]; sz += p[2];
+            sb += (float)s[16]; sg += (float)s[17]; sr += (float)s[18]; sa += (float)s[19];
+        }
+        const float cnt = (float)(b - a);
+        uint8_t* o = out + (size_t)total * 32;
+        const float q[4] = {sx / cnt, sy / cnt, sz / cnt, 1.0f};
+        memcpy(o, q, 16);
+        o[16] = (uint8_t)(uint32_t)(sb / cnt); o[17] = (uint8_t)(uint32_t)(sg / cnt); o[18] = (uint8_t)(uint32_t)(sr / cnt); o[19] = (uint8_t)(uint32_t)(sa / cnt);
+        memset(o + 20, 0, 12);
+        ++total; a = b;
+    }
+    free(keys); free(all);
+    return total;
 }

@@ -95,6 +95,30 @@ int orc_match_knn2_ratio(const uint8_t* q, int nq, int qstride, const uint8_t* t
     return n;
 }
 
+/* BFMatcher(NORM_HAMMING, crossCheck = true) as OpenCV 3.x implements it (SURVEY App. A6 "OpenCV-compat", recalled from
+ * batchDistance(..., crosscheck = true); unverified here: OpenCV is absent).  Only the REVERSE search is run: every train row t
+ * finds its nearest query row tq[t] (lowest query index on ties); then, for t ascending, `if tdist[t] < dist[q] { dist[q] =
+ * tdist[t]; nidx[q] = t; }` with dist[] starting at INT_MAX and nidx[] at -1; queries with nidx >= 0 are emitted in ascending
+ * order.  A query thus gets the best train AMONG THE TRAINS THAT VOTED FOR IT, which differs from the mutual nearest neighbour
+ * when the query's own nearest train prefers another query. */
+int orc_match_crosscheck_cv(const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, orc_dmatch* out)
+{
+    if (!(nq > 0 && nt > 0)) return 0;
+    int32_t* ti = (int32_t*)malloc(sizeof(int32_t) * nt); int32_t* td = (int32_t*)malloc(sizeof(int32_t) * nt);
+    int32_t* nidx = (int32_t*)malloc(sizeof(int32_t) * nq); int32_t* dist = (int32_t*)malloc(sizeof(int32_t) * nq);
+    orc_bf_nn(t, nt, tstride, q, nq, qstride, ti, td);
+    for (int i = 0; i < nq; ++i) { nidx[i] = -1; dist[i] = 0x7FFFFFFF; }
+    for (int j = 0; j < nt; ++j) {
+        const int i = ti[j];
+        if (i >= 0 && td[j] < dist[i]) { dist[i] = td[j]; nidx[i] = j; }
+    }
+    int n = 0;
+    for (int i = 0; i < nq; ++i)
+        if (nidx[i] >= 0) { out[n].queryIdx = i; out[n].trainIdx = nidx[i]; out[n].imgIdx = 0; out[n].distance = (float)dist[i]; ++n; }
+    free(ti); free(td); free(nidx); free(dist);
+    return n;
+}
+
 int orc_match_crosscheck(const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
                          orc_dmatch* out)                                   /* App. A6 mutual-NN, lowest-index ties both ways */
 {

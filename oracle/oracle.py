@@ -332,6 +332,14 @@ def match_crosscheck(q, t):
     return out[:n].copy()
 
 
+def match_crosscheck_cv(q, t):
+    """BFMatcher(NORM_HAMMING, crossCheck=True) the way OpenCV 3.x runs it (reverse search only)"""
+    q = _desc(q); t = _desc(t)
+    out = np.zeros(max(len(q), 1), DM_DTYPE)
+    n = lib().orc_match_crosscheck_cv(_p(q), len(q), 32, _p(t), len(t), 32, _p(out))
+    return out[:n].copy()
+
+
 # ---------------------------------------------------------------- MatchByDBoW (src/FeatureMatching.cpp:58-125, :192-208)
 class Vocabulary:
     """DBoW3::Vocabulary as a node table (bow_oracle.c): parent[nnodes], desc[nnodes][32], weight[nnodes], word[nnodes]"""
@@ -445,3 +453,17 @@ def rgb_cloud(depth, bgr, cx, cy, fx, fy, depth_scale_yaml):
     out = np.zeros(w * h, CLOUD_DTYPE)
     lib().orc_rgb_cloud(_p(depth), w, _p(bgr), bgr.strides[0], w, h, cx, cy, fx, fy, float(np.float32(depth_scale_yaml)) / 65535.0, _p(out))
     return out
+
+
+def voxel_fuse(final_cloud, frame_cloud, this_trans, voxel_size):
+    """one key frame of Map::MapPointCloudFusion (src/Map.cpp:164-197): transform the frame's cloud by
+    Affine3f::Identity().rotate(R).translate(t), append it to the map, VoxelGrid-filter the whole -> the new map.
+    this_trans: 4x4 (row-major numpy) GetAbsPose().inverse()"""
+    fin = np.ascontiguousarray(final_cloud, CLOUD_DTYPE); frm = np.ascontiguousarray(frame_cloud, CLOUD_DTYPE)
+    T = np.ascontiguousarray(np.asarray(this_trans, np.float32).reshape(4, 4).T)        # Eigen::Matrix4f storage order
+    out = np.zeros(len(fin) + len(frm), CLOUD_DTYPE)
+    f = lib().orc_voxel_fuse
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
+    n = f(_p(fin), len(fin), _p(frm), len(frm), _p(T), float(voxel_size), _p(out))
+    return out[:n].copy()

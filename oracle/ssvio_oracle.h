@@ -84,6 +84,7 @@ int  orc_match_bruteforce(const uint8_t* q, int nq, int qstride, const uint8_t* 
                           orc_dmatch* out);                                            /* :20-55; returns #matches */
 int  orc_match_knn2_ratio(const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
                           int threshold, float nn_ratio, orc_dmatch* out);             /* :85-112 over all rows */
+int  orc_match_crosscheck_cv(const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, orc_dmatch* out);
 int  orc_match_crosscheck(const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
                           orc_dmatch* out);                                            /* App. A6 mutual-NN */
 /* MatchByProject (:128-189): project p3d with R, t, K; 2-NN among the train keypoints inside the +-radian window */
@@ -124,6 +125,8 @@ void orc_manage_map_points(const orc_keypoint* kps, int nkp, const uint16_t* dep
                            const int32_t* obs, int nobs, int32_t* match_num, int32_t* map_point, float* world); /* src/Map.cpp:125-149, src/Frame.cpp:138-147 */
 void orc_rgb_cloud(const uint16_t* depth, int depth_stride_px, const uint8_t* bgr, int bgr_stride, int w, int h,
                    float cx, float cy, float fx, float fy, double depth_scale, uint8_t* out);  /* driver/Xtion_Driver.cpp:138-162, :219-229 */
+int orc_voxel_fuse(const uint8_t* final_cloud, int n_final, const uint8_t* frame_cloud, int n_frame,
+                   const float* this_trans, float voxel_size, uint8_t* out);                    /* src/Map.cpp:164-197, one key frame */
 #ifdef __cplusplus
 }
 #endif

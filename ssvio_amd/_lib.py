@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libssvio_gpu.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_GEOMETRY, ERR_NOGPU = 0, -1, -2, -3, -4, -5
 MAX_LEVELS = 16
-MODE_BRUTEFORCE, MODE_KNN2_RATIO, MODE_CROSSCHECK = 0, 1, 2
+MODE_BRUTEFORCE, MODE_KNN2_RATIO, MODE_CROSSCHECK, MODE_CROSSCHECK_CV = 0, 1, 2, 4
 NOALLOC_SCRATCH_BYTES = 32 << 20
 PAIR_ID_SEQUENTIAL, PAIR_ID_TRIANGULAR = 0, 1
 REC_DTYPE = np.dtype([("pair", "<i4"), ("n_matches", "<i4"), ("sum_dist", "<i8")])   # ssvio_pair_summary
@@ -82,6 +82,7 @@ SYMBOLS = {
     "ssvio_match_bruteforce": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "ssvio_match_knn2_ratio": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "ssvio_match_crosscheck": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "ssvio_match_crosscheck_cv": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "ssvio_match_knn2_raw": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ssvio_match_batch_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "ssvio_match_batch_summary_dev": (_i, [_vp, _i, _i, _vp]),
@@ -102,6 +103,12 @@ SYMBOLS = {
     "ssvio_in_match_vec": (_i, [_vp, _vp, _i, _i, _vp]),
     "ssvio_manage_map_points": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "ssvio_rgb_cloud": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, C.c_double, _vp]),
+    "ssvio_map_set": (_i, [_vp, _vp, _i]),
+    "ssvio_map_fuse": (_i, [_vp, _vp, _i, _vp, _f]),
+    "ssvio_map_fuse_dev": (_i, [_vp, _vp, _i, _vp, _f]),
+    "ssvio_map_fuse_frame": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, C.c_double, _vp, _f]),
+    "ssvio_map_fetch": (_i, [_vp, _vp, _i, _vp]),
+    "ssvio_map_device": (_i, [_vp, _vp, _vp]),
 }
 
 _lib = None

@@ -57,6 +57,10 @@ struct ssvio_matcher {
     // host entry points behind the matcher: small inputs (matches, keypoints, counts) and all outputs live in mapped host memory
     uint8_t* h_fin = nullptr; uint8_t* d_fin = nullptr; size_t finCap = 0;
     uint8_t* h_fout = nullptr; uint8_t* d_fout = nullptr; size_t foutCap = 0;
+    // the point-cloud map of Map::MapPointCloudFusion (capi_voxel.hip): current map in d_mapA (mapCount points of 32 bytes)
+    uint8_t* d_mapA = nullptr; size_t mapCapA = 0; uint8_t* d_mapB = nullptr; size_t mapCapB = 0; int mapCount = 0;
+    uint32_t* d_voxKeys = nullptr; size_t voxKeysCap = 0; uint8_t* d_voxTmp = nullptr; size_t voxTmpCap = 0;
+    void* d_voxState = nullptr; int* h_voxTotal = nullptr; int* d_voxTotal = nullptr;
     std::vector<uint8_t> stageQ, stageT;              // packed copies of strided descriptor rows
     std::vector<int32_t> h_pairs;                     // what d_pairs holds (an unchanged pair list is not uploaded again)
     KernelProfiler prof; std::string profOnly;

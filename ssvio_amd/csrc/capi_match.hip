@@ -51,15 +51,17 @@ int match_plan(int maxQ, int maxT, int npairs, int mode, size_t limitEntries, Ma
     p.small = knn2_small_applies(maxQ, maxT, npairs); p.smallRev = false;
     if (p.small) { p.nChunks = 1; p.chunkRows = maxT; }
     p.nChunksR = 0; p.chunkRowsR = 0;
-    if (mode == SSVIO_MODE_CROSSCHECK) {
+    const bool rev = mode == SSVIO_MODE_CROSSCHECK || mode == SSVIO_MODE_CROSSCHECK_CV;
+    if (mode == SSVIO_MODE_CROSSCHECK_CV) { p.nChunks = 1; p.chunkRows = maxT; p.small = false; }     // no forward search: the forward list holds the votes
+    if (rev) {
         pick_chunks(maxT, maxQ, npairs, p.nChunksR, p.chunkRowsR);
         p.smallRev = knn2_small_applies(maxT, maxQ, npairs);
         if (p.smallRev) { p.nChunksR = 1; p.chunkRowsR = maxQ; }
     }
     const size_t per = (size_t)npairs * p.maxRows;
     if (limitEntries) {
-        const size_t lim = mode == SSVIO_MODE_CROSSCHECK ? limitEntries / 2 : limitEntries;
-        if (per > lim) { set_error("%d pairs x %d rows need %zu bytes of scratch, the fixed scratch holds %zu", npairs, p.maxRows, per * 8 * (mode == SSVIO_MODE_CROSSCHECK ? 2 : 1), limitEntries * 8); return SSVIO_ERR_CAPACITY; }
+        const size_t lim = rev ? limitEntries / 2 : limitEntries;
+        if (per > lim) { set_error("%d pairs x %d rows need %zu bytes of scratch, the fixed scratch holds %zu", npairs, p.maxRows, per * 8 * (rev ? 2 : 1), limitEntries * 8); return SSVIO_ERR_CAPACITY; }
         auto fit = [&](int& nChunks, int& chunkRows, int rowsT) {
             if ((size_t)nChunks * per <= lim) return;
             const int want = (int)(lim / per);
@@ -67,7 +69,7 @@ int match_plan(int maxQ, int maxT, int npairs, int mode, size_t limitEntries, Ma
             nChunks = std::max(1, (rowsT + chunkRows - 1) / chunkRows);
         };
         fit(p.nChunks, p.chunkRows, maxT);
-        if (mode == SSVIO_MODE_CROSSCHECK) fit(p.nChunksR, p.chunkRowsR, maxQ);
+        if (rev) fit(p.nChunksR, p.chunkRowsR, maxQ);
     }
     p.partialEntries = (size_t)p.nChunks * per; p.partialRevEntries = (size_t)p.nChunksR * per;
     return SSVIO_OK;
@@ -86,7 +88,7 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
     a.qSetStrideRows = qStrideRows; a.tSetStrideRows = tStrideRows;
     a.qcounts = d_qcounts; a.tcounts = d_tcounts; a.pairs = d_pairs; a.swap = 0;
     a.nChunks = p.nChunks; a.chunkRows = p.chunkRows; a.partial = partial; a.maxRows = p.maxRows;
-    {
+    if (mode != SSVIO_MODE_CROSSCHECK_CV) {
         ProfScope ps(prof, "k_hamming_knn2", s);
         if (p.small) launch_knn2_small(a, maxQ, npairs, s); else launch_knn2(a, maxQ, npairs, s);
         SSVIO_HIP(hipGetLastError());
@@ -96,7 +98,7 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
     f.qcounts = d_qcounts; f.tcounts = d_tcounts; f.pairs = d_pairs;
     f.mode = mode; f.threshold = m->threshold; f.nnRatio = m->nnRatio;
     f.out = out; f.nout = nout; f.raw = raw;
-    if (mode == SSVIO_MODE_CROSSCHECK) {
+    if (mode == SSVIO_MODE_CROSSCHECK || mode == SSVIO_MODE_CROSSCHECK_CV) {
         MatchArgs r = a;
         r.qdesc = (const uint4*)d_tdesc; r.tdesc = (const uint4*)d_qdesc;
         r.qSetStrideRows = tStrideRows; r.tSetStrideRows = qStrideRows;
@@ -130,7 +132,7 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
     rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
     if (mode == 3) { rc = grow(m->d_raw, m->rawCap, (size_t)npairs * 3 * p.maxRows, s); if (rc) return rc; }
     else { rc = grow(m->d_out, m->outCap, (size_t)npairs * p.maxRows, s); if (rc) return rc; }
-    if (mode == SSVIO_MODE_CROSSCHECK) { rc = grow(m->d_partialRev, m->partialRevCap, p.partialRevEntries, s); if (rc) return rc; }
+    if (p.partialRevEntries) { rc = grow(m->d_partialRev, m->partialRevCap, p.partialRevEntries, s); if (rc) return rc; }
     rc = match_launch(m, p, d_qdesc, qStrideRows, d_qcounts, d_tdesc, tStrideRows, d_tcounts, d_pairs, npairs, maxQ, maxT, mode,
                       m->d_partial, m->d_partialRev, outTo ? outTo : m->d_out, noutTo ? noutTo : m->d_nout, rawTo ? rawTo : m->d_raw, true);
     if (rc) return rc;
@@ -254,6 +256,7 @@ void ssvio_matcher_destroy(ssvio_matcher* m)
     dfree(m->d_p3d); dfree(m->d_p2d); dfree(m->d_cand); dfree(m->d_keep);
     dfree(m->d_bowWord); dfree(m->d_bowNode); dfree(m->d_bowWeight); dfree(m->d_gnode); dfree(m->d_keepNode); dfree(m->d_sortIdx); dfree(m->d_sortNode);
     dfree(m->d_frameIn); dfree(m->d_frameOut); dfree(m->d_table);
+    dfree(m->d_mapA); dfree(m->d_mapB); dfree(m->d_voxKeys); dfree(m->d_voxTmp); dfree(m->d_voxState); hfree(m->h_voxTotal);
     hfree(m->h_counts2); hfree(m->h_result); hfree(m->h_descm); hfree(m->h_bowm); hfree(m->h_fin); hfree(m->h_fout);
     if (m->own) (void)hipStreamDestroy(m->own);
     delete m;
@@ -305,6 +308,10 @@ int ssvio_match_knn2_ratio(ssvio_matcher* m, const uint8_t* q, int nq, int qstri
 int ssvio_match_crosscheck(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
                            ssvio_dmatch* out, int cap, int* n)
 { return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_CROSSCHECK, out, cap, n, nullptr, nullptr, nullptr); }
+
+int ssvio_match_crosscheck_cv(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
+                              ssvio_dmatch* out, int cap, int* n)
+{ return match_host(m, q, nq, qstride, t, nt, tstride, SSVIO_MODE_CROSSCHECK_CV, out, cap, n, nullptr, nullptr, nullptr); }
 
 int ssvio_match_knn2_raw(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride,
                          int32_t* idx, int32_t* d1, int32_t* d2)
@@ -368,7 +375,7 @@ int ssvio_match_batch_dev(ssvio_matcher* m, const void* d_desc, int set_stride_r
 {
     if (mt_check(m)) return SSVIO_ERR_INVALID;
     if (!d_desc || !d_counts || !pairs || npairs <= 0 || max_rows <= 0 || set_stride_rows < max_rows) { set_error("bad batch arguments"); return SSVIO_ERR_INVALID; }
-    if (mode < 0 || mode > 2) { set_error("mode must be 0..2"); return SSVIO_ERR_INVALID; }
+    if (mode < 0 || mode == 3 || mode > SSVIO_MODE_CROSSCHECK_CV) { set_error("mode must be SSVIO_MODE_BRUTEFORCE, _KNN2_RATIO, _CROSSCHECK or _CROSSCHECK_CV"); return SSVIO_ERR_INVALID; }
     if (max_rows > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
     SSVIO_HIP(hipSetDevice(m->device));
     int rc = SSVIO_OK;

@@ -40,7 +40,7 @@ extern "C" int ssvio_match_batch_dev_noalloc(ssvio_matcher* m, const void* d_des
     if (!d_desc || !d_counts || !d_pairs || !d_matches || !d_nmatches || npairs <= 0 || max_rows <= 0 || set_stride_rows < max_rows) {
         set_error("bad batch arguments"); return SSVIO_ERR_INVALID;
     }
-    if (mode < 0 || mode > 2) { set_error("mode must be 0..2"); return SSVIO_ERR_INVALID; }
+    if (mode < 0 || mode == 3 || mode > SSVIO_MODE_CROSSCHECK_CV) { set_error("mode must be SSVIO_MODE_BRUTEFORCE, _KNN2_RATIO, _CROSSCHECK or _CROSSCHECK_CV"); return SSVIO_ERR_INVALID; }
     if (max_rows > (1 << 23)) { set_error("more than 2^23 rows per set"); return SSVIO_ERR_INVALID; }
     void* base = nullptr;
     {
@@ -53,7 +53,7 @@ extern "C" int ssvio_match_batch_dev_noalloc(ssvio_matcher* m, const void* d_des
     if (rc) return rc;                                           // SSVIO_ERR_CAPACITY: beyond the fixed scratch, nothing was launched
     SSVIO_HIP(hipSetDevice(m->device));
     uint2* partial = (uint2*)base;
-    uint2* partialRev = mode == SSVIO_MODE_CROSSCHECK ? partial + (size_t)SSVIO_NOALLOC_SCRATCH_BYTES / sizeof(uint2) / 2 : nullptr;
+    uint2* partialRev = p.partialRevEntries ? partial + (size_t)SSVIO_NOALLOC_SCRATCH_BYTES / sizeof(uint2) / 2 : nullptr;
     return match_launch(m, p, (const uint8_t*)d_desc, set_stride_rows, d_counts, (const uint8_t*)d_desc, set_stride_rows, d_counts,
                         d_pairs, npairs, max_rows, max_rows, mode, partial, partialRev, (ssvio_dmatch*)d_matches, d_nmatches, nullptr,
                         /*profile=*/false);

@@ -226,6 +226,10 @@ __global__ __launch_bounds__(256) void k_match_merge(uint2* partial, int nChunks
 //   mode 1: Threshold / NNRatio acceptance (src/FeatureMatching.cpp:104-111)
 //   mode 2: mutual nearest neighbour
 //   mode 3: raw (idx, d1, d2) triples, no filtering
+//   mode 4: BFMatcher(crossCheck = true) the way OpenCV 3.x runs it (SURVEY App. A6 "OpenCV-compat"): only the reverse search
+//           exists; every train row votes for its nearest query, a query keeps the closest of its voters (lowest train index on
+//           ties).  The votes are scattered with atomicMin on the key (dist << 23 | trainIdx) into the pair's otherwise unused
+//           forward list.
 __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
 {
     __shared__ int wsum[4];
@@ -249,6 +253,17 @@ __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
         }
         return;
     }
+    uint32_t* vote = (uint32_t*)const_cast<uint2*>(P);           // mode 4: [nq] best voter key per query
+    if (a.mode == SSVIO_MODE_CROSSCHECK_CV) {
+        for (int i = tid; i < nq; i += 256) __hip_atomic_store(&vote[i], kKeyInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        for (int t = tid; t < nt; t += 256) {
+            uint32_t r1, r2; merge_chunks(PR, a.nChunksRev, a.maxRows, t, r1, r2);
+            const uint32_t q = r1 & 0x7FFFFF;
+            if (r1 != kKeyInit && q < (uint32_t)nq) atomicMin(&vote[q], (r1 & ~0x7FFFFFu) | (uint32_t)t);
+        }
+        __syncthreads();
+    }
     int minD = 1 << 20;
     if (a.mode == 0) {
         if (tid == 0) sMin = 1 << 20;
@@ -266,7 +281,10 @@ __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
     for (int i0 = 0; i0 < nq; i0 += 256) {
         const int i = i0 + tid;
         bool keep = false; uint32_t k1 = kKeyInit, k2 = kKeyInit;
-        if (i < nq) {
+        if (i < nq && a.mode == SSVIO_MODE_CROSSCHECK_CV) {
+            k1 = __hip_atomic_load(&vote[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            keep = k1 != kKeyInit;
+        } else if (i < nq) {
             merge_chunks(P, a.nChunks, a.maxRows, i, k1, k2);
             const int d1 = (int)(k1 >> 23), d2 = min((int)(k2 >> 23), 256);
             if (a.mode == 0) keep = d1 < lim;

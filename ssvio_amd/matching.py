@@ -60,6 +60,11 @@ class FeatureMatching:
         m = self._call(L.lib().ssvio_match_crosscheck, desp1, desp2)
         return len(m) > 0, m
 
+    def MatchByCrossCheckCV(self, desp1, desp2):
+        """BFMatcher(NORM_HAMMING, crossCheck=True) the way OpenCV 3.x computes it (OpenCV-compat mode)"""
+        m = self._call(L.lib().ssvio_match_crosscheck_cv, desp1, desp2)
+        return len(m) > 0, m
+
     def MatchByProject(self, vp3d1, desp1, vp2d2, desp2, radian, K, R, t):
         """include/FeatureMatching.h:30-32, src/FeatureMatching.cpp:128-189: vp3d1 [n1][3] reference points with
         descriptors desp1, vp2d2 [n2][2] keypoints with descriptors desp2, K / R 3x3, t 3 (float64)"""
@@ -163,6 +168,39 @@ class FeatureMatching:
         out = np.zeros(w * h, L.CLOUD_DTYPE)
         L.check(L.lib().ssvio_rgb_cloud(self._h, L.ptr(depth), w, L.ptr(bgr), bgr.strides[0], w, h, L.ptr(c),
                                         float(np.float32(depth_scale_yaml)) / 65535.0, L.ptr(out)))
+        return out
+
+    # ---- Map::MapPointCloudFusion (src/Map.cpp:164-197): the map stays in HBM, one call per key frame
+    @staticmethod
+    def _trans(this_trans):
+        return np.ascontiguousarray(np.asarray(this_trans, np.float32).reshape(4, 4).T)       # Eigen::Matrix4f storage order
+
+    def MapSet(self, points=None):
+        pts = np.zeros(0, L.CLOUD_DTYPE) if points is None else np.ascontiguousarray(points, L.CLOUD_DTYPE)
+        L.check(L.lib().ssvio_map_set(self._h, L.ptr(pts) if len(pts) else None, len(pts)))
+
+    def MapFuse(self, cloud, this_trans, voxel_size):
+        """one key frame of the loop: transform (p' = R*p + R*t as written, :175-181), append, VoxelGrid(voxel_size)"""
+        T = self._trans(this_trans)
+        if hasattr(cloud, "data_ptr"):                                # a device cloud (torch tensor of 32-byte records)
+            n = cloud.numel() * cloud.element_size() // 32
+            L.check(L.lib().ssvio_map_fuse_dev(self._h, L.ptr(cloud), n, L.ptr(T), float(voxel_size)))
+        else:
+            c = np.ascontiguousarray(cloud, L.CLOUD_DTYPE)
+            L.check(L.lib().ssvio_map_fuse(self._h, L.ptr(c) if len(c) else None, len(c), L.ptr(T), float(voxel_size)))
+
+    def MapFuseFrame(self, depth, bgr, cam, depth_scale_yaml, this_trans, voxel_size):
+        depth = np.ascontiguousarray(depth, np.uint16); bgr = np.ascontiguousarray(bgr, np.uint8); c = self._cam(cam); T = self._trans(this_trans)
+        h, w = depth.shape
+        L.check(L.lib().ssvio_map_fuse_frame(self._h, L.ptr(depth), w, L.ptr(bgr), bgr.strides[0], w, h, L.ptr(c),
+                                             float(np.float32(depth_scale_yaml)) / 65535.0, L.ptr(T), float(voxel_size)))
+
+    def MapFetch(self):
+        n = C.c_int(0)
+        L.check(L.lib().ssvio_map_fetch(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, L.CLOUD_DTYPE)
+        if n.value:
+            L.check(L.lib().ssvio_map_fetch(self._h, L.ptr(out), n.value, C.byref(n)))
         return out
 
     def TrackMapPoints(self, last_match_vec, this_match_vec):

@@ -38,6 +38,14 @@ int main(int argc, char** argv)
         orb->keepPyramid = true;
         orb->Extract(a, cv::Mat(), ka, da);
         orb->Extract(b, cv::Mat(), kb, db);
+        {   // a non-8UC1 image (the reference asserts, src/Feature.cpp:511): no exception, outputs empty, the status says why
+            cv::Mat c3(h / 3, w, CV_8UC3, raw.data(), (size_t)w * 3);
+            std::vector<cv::KeyPoint> kx(5); cv::Mat dx(4, 32, CV_8U);
+            orb->Extract(c3, cv::Mat(), kx, dx);
+            if (orb->lastStatus() != SSVIO_ERR_INVALID || !kx.empty() || !dx.empty()) { fprintf(stderr, "wrong-type contract broken\n"); return 1; }
+            orb->Extract(a, cv::Mat(), kx, dx);
+            if (orb->lastStatus() != SSVIO_OK || kx.size() != ka.size()) { fprintf(stderr, "extractor unusable after a wrong-type call\n"); return 1; }
+        }
         std::vector<cv::DMatch> m;
         const bool ok = fm->MatchByBruteForce(db, da, m);
         std::vector<cv::DMatch> m2; fm->MatchByKnnRatio(db, da, m2);

@@ -330,3 +330,71 @@ def test_match_dbow_unsorted_path_and_large_sets(mods, monkeypatch):
     monkeypatch.setenv("SSVIO_DBOW_UNSORTED", "1")
     assert np.array_equal(_bytes(fm.MatchByDBoW(q[:900], t[:1000], levelsup=1)[1]), _bytes(small))      # same inputs, unsorted path
     fm.close(); v.close()
+
+
+def _pose(seed):
+    rng = np.random.default_rng(seed)
+    a, b, c = rng.uniform(-0.3, 0.3, 3)
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1.0, 0], [-np.sin(b), 0, np.cos(b)]])
+    Rx = np.array([[1.0, 0, 0], [0, np.cos(c), -np.sin(c)], [0, np.sin(c), np.cos(c)]])
+    T = np.eye(4); T[:3, :3] = Rz @ Ry @ Rx; T[:3, 3] = rng.uniform(-0.5, 0.5, 3)
+    return T.astype(np.float32)
+
+
+@pytest.mark.parametrize("h,w,voxel", [(120, 160, 0.01), (240, 320, 0.01), (240, 320, 0.05), (37, 53, 0.3)])
+def test_map_point_cloud_fusion_equals_oracle(mods, h, w, voxel):
+    """Map::MapPointCloudFusion (src/Map.cpp:164-197) over four key frames: the map after every iteration, byte for byte.
+    Parity unpinned (PCL restated in the oracle).  The zero-depth holes of every frame land on one point: a run of thousands
+    of points in one voxel (the wave-wide summation path)."""
+    S, synth, O, V, L = mods
+    cam = O.camera(160.5912 * w / 320, 120.4792 * h / 240, 253.0589 * w / 320, 254.1649 * h / 240, 10.0)
+    fm = S.FeatureMatching(None, {})
+    want = np.zeros(0, O.CLOUD_DTYPE)
+    for k in range(4):
+        depth = synth.depth_image(500 + k, h, w)
+        bgr = synth.to_rgb(synth.texture(600 + k, max(h, 16), max(w, 16))[:h, :w], k)
+        T = _pose(700 + k)
+        cloud = O.rgb_cloud(depth, bgr, float(cam[0]), float(cam[1]), float(cam[2]), float(cam[3]), 10.0)
+        want = O.voxel_fuse(want, cloud, T, voxel)
+        if k % 2 == 0:
+            fm.MapFuseFrame(depth, bgr, cam, 10.0, T, voxel)             # cloud built on the device from depth + BGR
+        else:
+            fm.MapFuse(cloud, T, voxel)                                  # host cloud
+        got = fm.MapFetch()
+        assert len(got) == len(want) and np.array_equal(got.view(np.uint8), want.view(np.uint8)), k
+    assert 0 < len(want) < 4 * h * w
+    # a map loaded from the host continues identically; an empty cloud re-filters the map (idempotent here)
+    fm.MapSet(want[: len(want) // 2])
+    fm.MapFuse(want[len(want) // 2:], np.eye(4), voxel)
+    again = O.voxel_fuse(want[: len(want) // 2], want[len(want) // 2:], np.eye(4), voxel)
+    assert np.array_equal(fm.MapFetch().view(np.uint8), again.view(np.uint8))
+    fm.MapSet(None)
+    assert len(fm.MapFetch()) == 0
+    fm.close()
+
+
+def test_map_fusion_edge_cases(mods):
+    import torch
+    S, synth, O, V, L = mods
+    fm = S.FeatureMatching(None, {})
+    I = np.eye(4, dtype=np.float32)
+    c = np.zeros(5, O.CLOUD_DTYPE); c["w"] = 1; c["a"] = 255
+    c["x"] = [0.0, 100.0, 1e-4, 0.02, 0.0201]; c["y"][1] = 100.0; c["z"][1] = 100.0; c["r"] = [1, 2, 3, 4, 5]
+    fm.MapFuse(c, I, 0.01)                                               # 10^4 cells per axis: indices overflow, the input comes back
+    assert np.array_equal(fm.MapFetch().view(np.uint8), O.voxel_fuse(c[:0], c, I, 0.01).view(np.uint8)) and len(fm.MapFetch()) == 5
+    fm.MapSet(None)
+    fm.MapFuse(torch.from_numpy(c.view(np.uint8).reshape(-1, 32)).cuda(), I, 1.0)          # a device cloud
+    assert np.array_equal(fm.MapFetch().view(np.uint8), O.voxel_fuse(c[:0], c, I, 1.0).view(np.uint8))
+    fm.MapSet(None)
+    fm.MapFuse(c[:0], I, 0.01)
+    assert len(fm.MapFetch()) == 0
+    bad = c.copy(); bad["x"][2] = np.nan
+    with pytest.raises(S.SsvioError):
+        fm.MapFuse(bad, I, 0.01)
+    with pytest.raises(S.SsvioError):
+        fm.MapFuse(c, I, 0.0)
+    fm.MapSet(None)
+    fm.MapFuse(c, I, 0.01)                                               # the handle stays usable
+    assert len(fm.MapFetch()) == 5
+    fm.close()

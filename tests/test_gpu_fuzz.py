@@ -90,7 +90,7 @@ def test_random_match_shapes_equal_oracle(nq, nt, seed):
     fm.close()
 
 
-@pytest.mark.parametrize("seed,mode", [(1, 0), (2, 1), (3, 2), (4, 0)])
+@pytest.mark.parametrize("seed,mode", [(1, 0), (2, 1), (3, 2), (4, 0), (5, 4)])
 def test_ragged_batches_equal_oracle(seed, mode):
     """device-resident batch with sets of very different sizes (including empty ones) and repeated / self pairs"""
     import torch
@@ -114,7 +114,7 @@ def test_ragged_batches_equal_oracle(seed, mode):
     fm.match_batch_dev(d_desc, stride, stride, d_cnt, pairs, mode)
     fm.sync()
     out, n = fm.fetch_batch()
-    ref = [O.match_bruteforce, lambda a, c: O.match_knn2_ratio(a, c, 50, 0.6), O.match_crosscheck][mode]
+    ref = {0: O.match_bruteforce, 1: lambda a, c: O.match_knn2_ratio(a, c, 50, 0.6), 2: O.match_crosscheck, 4: O.match_crosscheck_cv}[mode]
     for p, (a, c) in enumerate(pairs):
         want = ref(sets[a], sets[c])
         assert n[p] == len(want) and np.array_equal(out[p, :n[p]].view(np.uint8), want.view(np.uint8)), (p, counts[a], counts[c])

@@ -35,6 +35,28 @@ def test_all_modes_match_oracle(mods, fm, nq, nt):
     assert np.array_equal(m.view(np.uint8), O.match_knn2_ratio(q, t, 50, 0.6).view(np.uint8))
     ok, m = fm.MatchByCrossCheck(q, t)
     assert np.array_equal(m.view(np.uint8), O.match_crosscheck(q, t).view(np.uint8))
+    ok, m = fm.MatchByCrossCheckCV(q, t)
+    assert np.array_equal(m.view(np.uint8), O.match_crosscheck_cv(q, t).view(np.uint8)) and ok == (len(m) > 0)
+
+
+def test_crosscheck_cv_differs_from_mutual_nn_where_it_should(mods, fm):
+    """OpenCV's cross-check keeps, per query, the best train among the trains that voted for it"""
+    S, synth, O = mods
+    def row(nbits):
+        bits = np.zeros(256, np.uint8); bits[:nbits] = 1
+        return np.packbits(bits, bitorder="little")
+    # queries q0 = 0 bits, q1 = 10 bits; trains t0 = 4 bits (nearest to q0: d 4; to q1: d 6), t1 = 30 bits (d 30 / 20 -> votes q1)
+    q = np.stack([row(0), row(10)]); t = np.stack([row(4), row(30)])
+    ok, cv = fm.MatchByCrossCheckCV(q, t)
+    ok, mu = fm.MatchByCrossCheck(q, t)
+    assert [(m["queryIdx"], m["trainIdx"], m["distance"]) for m in cv] == [(0, 0, 4.0), (1, 1, 20.0)]     # q1 keeps its only voter
+    assert [(m["queryIdx"], m["trainIdx"], m["distance"]) for m in mu] == [(0, 0, 4.0)]                   # q1's nearest (t0) prefers q0
+    assert np.array_equal(cv.view(np.uint8), O.match_crosscheck_cv(q, t).view(np.uint8))
+    # ties: two identical trains vote for the same query -> the lower train index stays; distance 256 still votes
+    q = np.stack([row(0)]); t = np.stack([row(256), row(256), row(256)])
+    ok, cv = fm.MatchByCrossCheckCV(q, t)
+    assert [(m["queryIdx"], m["trainIdx"], m["distance"]) for m in cv] == [(0, 0, 256.0)]
+    assert np.array_equal(cv.view(np.uint8), O.match_crosscheck_cv(q, t).view(np.uint8))
 
 
 def test_ties_resolve_to_lowest_index(mods, fm):
@@ -188,7 +210,7 @@ def test_count_above_max_rows_is_clamped_and_neighbours_stay_exact(mods):
     counts = [len(d) for d in sets]; counts[2] = 5000             # the bad count
     pairs = np.array([[0, 1], [2, 3], [1, 2], [4, 0], [3, 4], [2, 2]], np.int32)
     for mode, ref in ((L.MODE_BRUTEFORCE, O.match_bruteforce), (L.MODE_KNN2_RATIO, lambda a, c: O.match_knn2_ratio(a, c, 50, 0.6)),
-                      (L.MODE_CROSSCHECK, O.match_crosscheck)):
+                      (L.MODE_CROSSCHECK, O.match_crosscheck), (L.MODE_CROSSCHECK_CV, O.match_crosscheck_cv)):
         fm = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
         d_desc = torch.from_numpy(buf).cuda(); d_cnt = torch.tensor(counts, dtype=torch.int32).cuda()
         fm.match_batch_dev(d_desc, stride, max_rows, d_cnt, pairs, mode)

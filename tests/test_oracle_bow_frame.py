@@ -294,3 +294,57 @@ def test_rgb_cloud_known_values(oracle):
     z = oracle.rgb_cloud(raw, np.zeros((1, 65535, 3), np.uint8), 0, 0, 1, 1, 10.0)["z"]
     assert np.array_equal(z, (raw[0].astype(np.float64) * (10.0 / 65535.0)).astype(np.float32))
     assert (z != raw[0].astype(np.float32) * s32).any()
+
+
+def _cloud(oracle, xyz, rgb=None):
+    c = np.zeros(len(xyz), oracle.CLOUD_DTYPE)
+    xyz = np.asarray(xyz, np.float32).reshape(-1, 3)
+    c["x"], c["y"], c["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    c["w"] = 1.0; c["a"] = 255
+    if rgb is not None:
+        rgb = np.asarray(rgb, np.uint8).reshape(-1, 3)
+        c["r"], c["g"], c["b"] = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    return c
+
+
+def test_voxel_fuse_known_values(oracle):
+    """Map::MapPointCloudFusion (src/Map.cpp:164-197), hand-derived.  Parity unpinned: PCL restated (oracle/frame_oracle.c)."""
+    f = np.float32
+    I = np.eye(4, dtype=np.float32)
+    # two points in one 1-cm voxel -> centroid; colour channels averaged and truncated; data[3] = 1, alpha 255
+    c = _cloud(oracle, [[0.001, 0.002, 0.003], [0.004, 0.006, 0.008], [0.5, 0.5, 0.5]], [[10, 20, 30], [11, 21, 33], [1, 2, 3]])
+    r = oracle.voxel_fuse(c[:0], c, I, 0.01)
+    assert len(r) == 2
+    assert r["x"][0] == (f(0.001) + f(0.004)) / f(2) and r["y"][0] == (f(0.002) + f(0.006)) / f(2) and r["z"][0] == (f(0.003) + f(0.008)) / f(2)
+    assert (r["r"][0], r["g"][0], r["b"][0], r["a"][0]) == (10, 20, 31, 255) and (r["w"] == 1.0).all() and (r["pad"] == 0).all()
+    assert (r["x"][1], r["r"][1]) == (f(0.5), 1)
+    # a point exactly on a leaf boundary belongs to the upper voxel (floor): 0.02 * 100 = 2.0 -> cell 2; 0.0199 -> cell 1
+    c = _cloud(oracle, [[0.0, 0, 0], [0.0199, 0, 0], [0.02, 0, 0], [0.0201, 0, 0]])
+    r = oracle.voxel_fuse(c[:0], c, I, 0.01)
+    assert len(r) == 3 and r["x"][2] == (f(0.02) + f(0.0201)) / f(2)
+    # output order is ascending voxel index x + y * dx + z * dx * dy, not input order
+    c = _cloud(oracle, [[0.0, 0.0, 0.05], [0.0, 0.05, 0.0], [0.05, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    r = oracle.voxel_fuse(c[:0], c, I, 0.01)
+    assert r["x"].tolist() == [0.0, f(0.05), 0.0, 0.0] and r["y"].tolist() == [0.0, 0.0, f(0.05), 0.0] and r["z"].tolist() == [0.0, 0.0, 0.0, f(0.05)]
+    # the transform as written: Affine3f::Identity().rotate(R).translate(t) = R * (p + t), NOT R * p + t (:177-181)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]               # +90 degrees about z
+    T[:3, 3] = [1.0, 0.0, 0.0]
+    c = _cloud(oracle, [[2.0, 0.0, 0.0]])
+    r = oracle.voxel_fuse(c[:0], c, T, 0.01)
+    assert (r["x"][0], r["y"][0], r["z"][0]) == (0.0, 3.0, 0.0)      # R * ((2,0,0) + (1,0,0)); R * p + t would be (1, 2, 0)
+    # the map's own points are not transformed again, and they come first in a voxel's sum
+    m0 = _cloud(oracle, [[0.0, 3.0011, 0.0]])
+    r = oracle.voxel_fuse(m0, c, T, 0.01)
+    assert len(r) == 1 and r["y"][0] == (f(3.0011) + f(3.0)) / f(2)
+    # sums are sequential float additions in cloud order: (2^24 + 1) + 1 = 2^24 in float, (1 + 1) + 2^24 = 2^24 + 2
+    big = _cloud(oracle, [[2.0 ** 24, 0, 0], [1.0, 0, 0], [1.0, 0, 0]])
+    r = oracle.voxel_fuse(big[:0], big, I, 1e9)
+    assert len(r) == 1 and r["x"][0] == f(2.0 ** 24) / f(3)
+    r = oracle.voxel_fuse(big[:0], big[::-1], I, 1e9)
+    assert len(r) == 1 and r["x"][0] == f(2.0 ** 24 + 2) / f(3)
+    # a leaf too small for 32-bit voxel indices: PCL warns and returns the input unchanged
+    far = _cloud(oracle, [[0, 0, 0], [100.0, 100.0, 100.0], [0.0001, 0, 0]])
+    r = oracle.voxel_fuse(far[:0], far, I, 0.01)
+    assert len(r) == 3 and np.array_equal(r["x"], far["x"])
+    assert len(oracle.voxel_fuse(c[:0], c[:0], I, 0.01)) == 0

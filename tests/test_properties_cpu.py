@@ -46,6 +46,18 @@ def test_matcher_oracle_invariants(oracle, seed, nq, nt, dup):
     c = oracle.match_crosscheck(q, t)
     for a, b in zip(c["queryIdx"], c["trainIdx"]):
         assert D[a].argmin() == b and D[:, b].argmin() == a
+    # the OpenCV-compat cross-check from its definition: trains vote for their nearest query, a query keeps
+    # its closest voter (lowest train index on ties); every mutual-NN match is among them with the same train or a closer voter
+    cv = oracle.match_crosscheck_cv(q, t)
+    votes = D.argmin(0)
+    want = []
+    for a in range(nq):
+        voters = np.flatnonzero(votes == a)
+        if len(voters):
+            b = voters[np.argmin(D[a, voters])]
+            want.append((a, int(b), float(D[a, b])))
+    assert [(int(m["queryIdx"]), int(m["trainIdx"]), float(m["distance"])) for m in cv] == want
+    assert set(c["queryIdx"].tolist()) <= set(cv["queryIdx"].tolist())
 
 
 @settings(**CFG)

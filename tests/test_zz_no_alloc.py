@@ -43,7 +43,7 @@ def test_noalloc_equals_allocating_entry_point_on_two_calls_in_a_row():
     calls = [([1300, 1024, 0, 700, 1299, 65, 1, 911, 1300, 512], 1344, 1300, 40, 11),
              ([300, 17, 256, 0, 299, 64], 320, 300, 9, 12)]
     for mode, ref in ((L.MODE_BRUTEFORCE, O.match_bruteforce), (L.MODE_KNN2_RATIO, lambda a, c: O.match_knn2_ratio(a, c, 50, 0.6)),
-                      (L.MODE_CROSSCHECK, O.match_crosscheck)):
+                      (L.MODE_CROSSCHECK, O.match_crosscheck), (L.MODE_CROSSCHECK_CV, O.match_crosscheck_cv)):
         for counts, stride, max_rows, npairs, seed in calls:
             rng = np.random.default_rng(seed + mode)
             buf = _sets(synth, seed, counts, stride)
