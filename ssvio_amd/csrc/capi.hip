@@ -218,7 +218,7 @@ static void fill_klevels(const PyramidGeom& g, KLevels& k)
         KLevel& K = k.lv[l];
         K.w = L.w; K.h = L.h; K.pitch = L.pitch; K.offset = L.offset;
         K.nCols = L.nCols; K.nRows = L.nRows; K.wCell = L.wCell; K.hCell = L.hCell; K.cellBase = L.cellBase;
-        K.fastTileBase = L.fastTileBase; K.fastTilesX = L.fastTilesX; K.fastTileBaseT = L.fastTileBaseT;
+        K.fastTileBase = L.fastTileBase; K.fastTilesX = L.fastTilesX; K.fastTileBaseT = L.fastTileBaseT; K.fastTileH = L.fastTileH; K.fastTileHT = L.fastTileHT;
         K.blurStripBase = L.blurStripBase; K.blurStripsX = L.blurStripsX; K.blurIters = L.blurIters;
         K.quota = L.quota; K.kpSize = L.kpSize; K.scale = L.scale;
         K.rawBase = (unsigned)L.slotBase; K.rawCap = (unsigned)L.slotCap * L.nCols * L.nRows;

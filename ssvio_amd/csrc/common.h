@@ -15,6 +15,7 @@ constexpr int kEdge = 19;          // EDGE_THRESHOLD, src/Feature.cpp:14
 constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE, src/Feature.cpp:13
 constexpr int kMinBorder = 16;     // EDGE_THRESHOLD - 3, src/Feature.cpp:835
 constexpr int kPadX = 4;          // reflect-101 columns kept on both sides of every level row (for k_blur)
+constexpr int kFastX0 = 16;        // x of the first k_fast tile column (dword-aligned; the tested region starts at kEdge)
 constexpr int kMaxRoots = 8;       // quadtree roots per level = round(width / height) of the tested region (src/Feature.cpp:574)
 // Keypoints one level can deliver: the quadtree stops at >= quota nodes and a split adds at most 3 (quota + 3), but its
 // FIRST round splits every root whatever the quota (src/Feature.cpp:621-703: the size test follows the round), so a
@@ -46,8 +47,8 @@ struct LevelGeom {
     int quota;                // mnFeaturesPerLevel
     float scale;              // mvScaleFactor
     int kpSize;               // (int)(15*scale)
-    int fastTileBase, fastTilesX, fastTilesY;   // k_fast tiles (64 x 32 px)
-    int fastTileBaseT, fastTilesYT;             // ... and the tall form (64 x 64 px) used for large batches
+    int fastTileBase, fastTilesX, fastTilesY, fastTileH;   // k_fast tiles over the tested region: 64 px wide, fastTileH <= 32 rows
+    int fastTileBaseT, fastTilesYT, fastTileHT;            // ... and the tall form (<= 64 rows) used for large batches
     int blurStripBase, blurStripsX, blurStripsY, blurIters;   // k_blur strips: 120 px wide, 7*blurIters-6 rows tall
     size_t tabOffset;         // offset (in shorts) of this level's resize tables
 };
@@ -70,7 +71,7 @@ struct KLevel {
     int w, h, pitch;
     int nCols, nRows, wCell, hCell;
     int cellBase;
-    int fastTileBase, fastTilesX, fastTileBaseT;
+    int fastTileBase, fastTilesX, fastTileBaseT, fastTileH, fastTileHT;
     int blurStripBase, blurStripsX, blurIters;
     int quota, kpSize;
     float scale;

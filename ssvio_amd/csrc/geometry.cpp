@@ -101,10 +101,15 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
             L.blurStripsY = (L.h + (7 * L.blurIters - 6) - 1) / (7 * L.blurIters - 6);
         }
         L.blurStripBase = tiles; tiles += L.blurStripsX * L.blurStripsY;
-        L.fastTilesX = (L.w + 63) / 64; L.fastTilesY = (L.h + 31) / 32;
-        L.fastTileBase = ftiles; ftiles += L.fastTilesX * L.fastTilesY;
-        L.fastTilesYT = (L.h + 63) / 64;
-        L.fastTileBaseT = ftilesT; ftilesT += L.fastTilesX * L.fastTilesYT;
+        // k_fast tiles cover the tested region only: columns from kFastX0 = 16 (aligned) to w - 20, rows 19 .. h - 20 split evenly
+        {
+            const int cols = L.w - kEdge - kFastX0, rows = L.h - 2 * kEdge;          // both >= 24: a level holds at least one 30-px cell
+            L.fastTilesX = (cols + 63) / 64;
+            L.fastTilesY = (rows + 31) / 32; L.fastTileH = (rows + L.fastTilesY - 1) / L.fastTilesY;
+            L.fastTileBase = ftiles; ftiles += L.fastTilesX * L.fastTilesY;
+            L.fastTilesYT = (rows + 63) / 64; L.fastTileHT = (rows + L.fastTilesYT - 1) / L.fastTilesYT;
+            L.fastTileBaseT = ftilesT; ftilesT += L.fastTilesX * L.fastTilesYT;
+        }
         g.maxQuotaSum += level_sel_cap(L.quota);
     }
     g.frameBytes = off + 256;

@@ -330,9 +330,12 @@ void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int le
 // Survivors are appended (unordered) to the level's raw list with both flags (iniTh / minTh) and their
 // position in the reference's append order as key; cellIni[cell] is raised when a cell has an iniTh
 // survivor, which is what decides the minTh retry of src/Feature.cpp:875 (resolved by the consumer).
-constexpr int kFtW = 64;                     // output tile width; the height FH is 32 or 64 (template parameter)
+constexpr int kFtW = 64;                     // output tile width; the height is the level's th <= FH (FH = 32 or 64, template parameter)
 constexpr int kFtPitch = 72;                 // LDS row bytes: x0-4 .. x0+67
-// input rows y0-4 .. y0+FH+3 (FH + 8), score rows y0-1 .. y0+FH (FH + 2, same column layout as the input tile)
+// The tile grid of a level starts at (kFastX0, kEdge) = (16, 19): FAST is only evaluated in [19, w-20] x [19, h-20] (src/Feature.cpp:835-873:
+// windows inside [16, w-16) minus cv::FAST's 3-px rim), so no tile is spent on the untested border; x starts at 16 rather than 19 to
+// keep the row loads dword-aligned.  The rows of the tested region are split evenly over the level's tile rows (th <= FH each).
+// input rows y0-4 .. y0+th+3 (th + 8), score rows y0-1 .. y0+th (th + 2, same column layout as the input tile)
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 
@@ -366,27 +369,36 @@ __device__ __forceinline__ int find_fast_level(const KLevels& kl, int id)
     return level;
 }
 
+// LDS budget: the two work queues are sized for what frames deliver (~5 % of a tile's pixels pass the compass test, ~1.5 % are
+// corners), not for the worst case, so that 8 workgroups fit a CU (the kernel is bound by latency between its barriers, not by
+// issue: more resident workgroups is what makes it faster).  A tile that overflows a queue takes a dense loop over the score domain
+// for that phase instead -- same results, slower, rare (noise images).
+constexpr int kFtQueueCap = 2048, kFtCornerCap = 1024, kFtOutCap = 256;
+
 template <int FH>
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, size_t pyrFrameBytes, KLevels kl, int cellsPerFrame,
                                               size_t rawPerFrame, int iniTh, int minTh, uint2* __restrict__ raw,
                                               int* __restrict__ rawCount, int* __restrict__ cellIni, int tilesPerFrame, int batch)
 {
-    constexpr int kFtH = FH, kFtRows = FH + 8, kScRows = FH + 2;
+    constexpr int kFtRows = FH + 8, kScRows = FH + 2;
     constexpr int kLoadPasses = (kFtRows + 13) / 14, kScanPasses = (kScRows + 13) / 14;      // rows r0, r0+14, ... per thread
     __shared__ __attribute__((aligned(16))) uint32_t tile[kFtRows * kFtPitch / 4];
     __shared__ __attribute__((aligned(16))) uint32_t sc[kScRows * kFtPitch / 4];
-    __shared__ uint16_t queue[kScRows * kFtPitch];
-    __shared__ uint2 outbuf[kFtW * kFtH / 4];            // NMS survivors of one tile: no two are 8-adjacent within a cell
-    __shared__ int qn, on, obase;
+    __shared__ uint16_t queue[kFtQueueCap];              // pixels that pass the compass test (positions in the score tile)
+    __shared__ uint16_t cqueue[kFtCornerCap];            // ... of those, the corners (score >= the lower threshold): the NMS walks only these
+    __shared__ uint2 outbuf[kFtOutCap];                  // NMS survivors of one tile (beyond the capacity they are appended one by one)
+    __shared__ int qn, cn, on, obase;
     const int tid = threadIdx.x;
     int frame, tileId;
     xcd_frame_block(blockIdx.x, tilesPerFrame, batch, frame, tileId);
     const int level = find_fast_level<FH == 64>(kl, tileId);
     const KLevel& L = kl.lv[level];
     const int t = tileId - (FH == 64 ? L.fastTileBaseT : L.fastTileBase);
+    const int th = FH == 64 ? L.fastTileHT : L.fastTileH;              // rows of this level's tiles, <= FH
     const int tyi = t / L.fastTilesX, txi = t - tyi * L.fastTilesX;
     const int w = L.w, h = L.h, pitch = L.pitch;
-    const int x0 = txi * kFtW, y0 = tyi * kFtH;
+    const int x0 = kFastX0 + txi * kFtW, y0 = kEdge + tyi * th;
+    const int ftRows = th + 8, scRows = th + 2;
     const int tLow = min(iniTh, minTh);
     const uint8_t* img = pyr + (size_t)frame * pyrFrameBytes + L.offset;
     const int xMaxLoad = (w + 56) & ~3;                    // last dword that is still inside the row's slack
@@ -400,32 +412,36 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
         for (int k = 0; k < kLoadPasses; ++k) {
             const int r = r0 + 14 * k;
             const int yy = min(max(y0 - 4 + r, 0), h - 1);
-            ld[k] = (lane252 && r < kFtRows) ? *(const uint32_t*)(img + (size_t)yy * pitch + xoff) : 0u;
+            ld[k] = (lane252 && r < ftRows) ? *(const uint32_t*)(img + (size_t)yy * pitch + xoff) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < kLoadPasses; ++k) {
             const int r = r0 + 14 * k;
-            if (lane252 && r < kFtRows) tile[r * (kFtPitch / 4) + c0] = ld[k];
-            if (lane252 && r < kScRows) sc[r * (kFtPitch / 4) + c0] = 0;
+            if (lane252 && r < ftRows) tile[r * (kFtPitch / 4) + c0] = ld[k];
+            if (lane252 && r < scRows) sc[r * (kFtPitch / 4) + c0] = 0;
         }
     }
-    if (tid == 0) { qn = 0; on = 0; }
+    if (tid == 0) { qn = 0; cn = 0; on = 0; }
     __syncthreads();
     const uint8_t* tb = (const uint8_t*)tile;
+    // tested columns of this tile's score domain x0-1 .. x0+64, as positions in a score row (x = x0 - 4 + position)
+    const int cLo = max(x0 - 1, kEdge) - (x0 - 4), cHi = min(x0 + kFtW, w - kEdge - 1) - (x0 - 4);
     // phase 1, packed: a 9-arc always contains two ADJACENT compass pixels (ring 0,4,8,12); "some adjacent
     // compass pair in one class" == (down|up) & (left|right) per class.  Two pixels per packed-i16 register.
-    // Domain: score rows y0-1 .. y0+32 (r = 0..33), quad columns x0-4 .. x0+67 (pixels outside x0-1 .. x0+64 dropped).
+    // Domain: score rows y0-1 .. y0+th (r = 0..th+1), quad columns x0-4 .. x0+67 (pixels outside cLo .. cHi dropped).
     unsigned flags = 0;                                     // bit (8i+k): pixel i of this thread's quad of pass k survives (kScanPasses <= 5)
     const short2v T2 = short2v{(short)tLow, (short)tLow};
-    // tile (with its 1-px halo) entirely inside the tested region [19, w-20] x [19, h-20]?
-    const bool allValid = x0 - 1 >= kEdge && x0 + kFtW <= w - kEdge - 1 && y0 - 1 >= kEdge && y0 + kFtH <= h - kEdge - 1;
     const int qc = c0;
-    // pixels of the score domain x0-1 .. x0+64 only (quad columns 0 and 17 are partial); one sign byte per pixel
-    const uint32_t colMask = !lane252 ? 0u : (qc == 0 ? 0x80000000u : (qc == 17 ? 0x00000080u : 0x80808080u));
+    // One sign byte per pixel.  A thread's four columns are the same in every pass: their mask is built once.
+    uint32_t colMask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (lane252 && 4 * qc + i >= cLo && 4 * qc + i <= cHi) colMask |= 0x80u << (8 * i);
 #pragma unroll
     for (int k = 0; k < kScanPasses; ++k) {
+        if (14 * k >= scRows) break;                        // block-uniform: short tiles need fewer passes
         const int r = min(r0 + 14 * k, kScRows - 1);
-        const bool qlive = r0 + 14 * k < kScRows;
+        const int y = y0 - 1 + r;
+        const bool rowOk = r0 + 14 * k < scRows && y >= kEdge && y <= h - kEdge - 1;      // a tested row of this tile's score domain
         const int rowC = (r + 3) * (kFtPitch / 4);          // input row of score row r
         const uint32_t C = tile[rowC + qc], Lf = tile[rowC + max(qc - 1, 0)], Rt = tile[rowC + min(qc + 1, 17)];
         const uint32_t U = tile[rowC - 3 * (kFtPitch / 4) + qc], D = tile[rowC + 3 * (kFtPitch / 4) + qc];
@@ -444,16 +460,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
             sgn[hlf] = __builtin_bit_cast(uint32_t, (short2v)(T2 - __builtin_elementwise_max(v - A, B - v)));      // negative <=> passes
         }
         // the four sign bytes (pixels 0..3) in one dword
-        uint32_t f4 = __builtin_amdgcn_perm(sgn[1], sgn[0], 0x07050301u) & (qlive ? colMask : 0u);
-        if (!allValid && f4) {
-            const int y = y0 - 1 + r;
-            const bool rowOk = y >= kEdge && y <= h - kEdge - 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int xa = x0 + 4 * qc + i - 4;
-                if (!(rowOk && xa >= kEdge && xa <= w - kEdge - 1)) f4 &= ~(0x80u << (8 * i));
-            }
-        }
+        const uint32_t f4 = __builtin_amdgcn_perm(sgn[1], sgn[0], 0x07050301u) & (rowOk ? colMask : 0u);
         flags |= f4 >> (7 - k);
     }
     {   // one queue reservation per wave
@@ -476,15 +483,15 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
             unsigned f = flags;
             while (f) {
                 const int bit = __ffs(f) - 1; f &= f - 1;
-                queue[base++] = (uint16_t)(e0 + (bit & 7) * (14 * kFtPitch) + (bit >> 3));
+                if (base < kFtQueueCap) queue[base] = (uint16_t)(e0 + (bit & 7) * (14 * kFtPitch) + (bit >> 3));
+                ++base;
             }
         }
     }
     __syncthreads();
     const int nq = qn;
-    // phase 2: exact score of the queued pixels
-    for (int q = tid; q < nq; q += 256) {
-        const int p = queue[q];
+    // phase 2: exact score of the queued pixels; the corners among them go on to a second, dense queue
+    auto score = [&](int p) -> bool {
         const uint8_t* c = tb + p + 3 * kFtPitch;               // score row r <-> input row r + 3, same columns
         const int v = c[0];
         int d[16];
@@ -495,17 +502,49 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
         RING(12, -3)               RING(13, kFtPitch - 3)      RING(14, 2 * kFtPitch - 2)  RING(15, 3 * kFtPitch - 1)
 #undef RING
         const int s = arc9_score(d);
-        if (s >= tLow && s > 0) ((uint8_t*)sc)[p] = (uint8_t)s;
+        const bool corner = s >= tLow && s > 0;
+        if (corner) ((uint8_t*)sc)[p] = (uint8_t)s;
+        return corner;
+    };
+    // wave-aggregated append to the corner queue (entries beyond its capacity are only counted: phase 3 then goes dense)
+    auto push_corner = [&](bool corner, int p) {
+        const unsigned long long vote = __ballot(corner);
+        if (vote) {
+            const int lane = tid & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&cn, __popcll(vote));
+            base = __builtin_amdgcn_readfirstlane(base) + __popcll(vote & ((1ull << lane) - 1ull));
+            if (corner && base < kFtCornerCap) cqueue[base] = (uint16_t)p;
+        }
+    };
+    if (nq <= kFtQueueCap) {
+        for (int q0 = 0; q0 < nq; q0 += 256) {                  // waves whose 64 entries lie beyond nq skip the body
+            const int q = q0 + tid;
+            int p = 0; bool corner = false;
+            if (q < nq) { p = queue[q]; corner = score(p); }
+            push_corner(corner, p);
+        }
+    } else {
+        // the queue overflowed: every tested pixel of the score domain is scored (a superset of the queued ones; a pixel that fails
+        // the compass test has no 9-arc, so its score stays below the threshold exactly as if it had not been looked at)
+        for (int e0 = 0; e0 < scRows * kFtPitch; e0 += 256) {
+            const int e = e0 + tid;
+            const int r = (int)(__umul24(e, 14564u) >> 20), cidx = e - r * kFtPitch;
+            const int y = y0 - 1 + r;
+            bool corner = false;
+            if (e < scRows * kFtPitch && cidx >= cLo && cidx <= cHi && y >= kEdge && y <= h - kEdge - 1) corner = score(e);
+            push_corner(corner, e);
+        }
     }
     __syncthreads();
-    // phase 3: NMS inside the pixel's own cell, for the tile's own 64x32 pixels
+    // phase 3: NMS inside the pixel's own cell, for the tile's own 64 x th pixels
+    const int nc = cn;
     const uint8_t* sb = (const uint8_t*)sc;
-    for (int q = tid; q < nq; q += 256) {
-        const int p = queue[q];
+    auto nms = [&](int p) {
         const int s = sb[p];
         const int r = (int)(__umul24(p, 14564u) >> 20), cidx = p - r * kFtPitch;       // p / 72 for p < 33000
         const int lx = cidx - 4, ly = r - 1;
-        if (s == 0 || lx < 0 || lx >= kFtW || ly < 0 || ly >= kFtH) continue;
+        if (lx < 0 || lx >= kFtW || ly < 0 || ly >= th) return;            // halo pixels belong to the neighbouring tile
         const int x = x0 + lx, y = y0 + ly;
         const int gx = x - kEdge, gy = y - kEdge;                         // position inside the tested region
         const int cj = (int)(__umul24(gx, L.wCellMagic) >> 20), ci = (int)(__umul24(gy, L.hCellMagic) >> 20);       // exact gx / wCell for gx < 4096 (host-built magic)
@@ -523,16 +562,21 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
             const uint2 rec = make_uint2(((uint32_t)(fIni | fMin) << 30) | ((uint32_t)cell << 12) | ((uint32_t)ry << 6) | (uint32_t)rx,
                                          (uint32_t)(x - kMinBorder) | ((uint32_t)(y - kMinBorder) << 12) | ((uint32_t)s << 24));
             const int slot = atomicAdd(&on, 1);
-            if (slot < kFtW * kFtH / 4) outbuf[slot] = rec;
-            else {      // more survivors than one per 2x2 block (only possible along cell borders): append directly
+            if (slot < kFtOutCap) outbuf[slot] = rec;
+            else {      // beyond the staging buffer: append directly
                 const int g = atomicAdd(&rawCount[frame * kMaxLevels + level], 1);
                 if ((unsigned)g < L.rawCap) raw[(size_t)frame * rawPerFrame + L.rawBase + g] = rec;
             }
             if (fIni) cellIni[(size_t)frame * cellsPerFrame + L.cellBase + cell] = 1;
         }
+    };
+    if (nc <= kFtCornerCap) {
+        for (int q = tid; q < nc; q += 256) nms(cqueue[q]);
+    } else {
+        for (int e = tid; e < scRows * kFtPitch; e += 256) if (sb[e]) nms(e);
     }
     __syncthreads();
-    const int no = min(on, kFtW * kFtH / 4);
+    const int no = min(on, kFtOutCap);
     if (no == 0) return;
     if (tid == 0) obase = atomicAdd(&rawCount[frame * kMaxLevels + level], no);
     __syncthreads();

@@ -391,3 +391,41 @@ def test_two_levels_per_launch_for_small_batches(mods, w, h, sf, nl):
                 for l in range(nl):
                     assert np.array_equal(g.debug_level_image(l, frame=f), c.level_image(l)), (batch, l)
     g.close()
+
+
+@pytest.mark.parametrize("kind,w,h,batch", [("uniform", 320, 240, 1), ("uniform", 640, 480, 9), ("dots", 333, 270, 1), ("checker", 400, 300, 1)])
+def test_fast_queue_overflow_paths(mods, kind, w, h, batch):
+    """k_fast sizes its LDS work queues for ordinary frames (2048 compass candidates, 1024 corners per 64 x 64 tile); tiles that
+    overflow them take the dense loops.  Uniform noise overflows both (about a third of its pixels are corners), a 3-px checker
+    overflows the candidate queue only; every FAST candidate, score and the final keypoints must still equal the oracle's.
+    Small (one 64 x 32 tile form) and batched (64 x 64 form) launches."""
+    import torch
+    S, synth, O = mods
+    rng = np.random.default_rng(w + h)
+    if kind == "uniform":
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == "dots":
+        img = np.full((h, w), 20, np.uint8); img[::4, ::4] = 250; img[2::8, 2::8] = 0
+    else:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.where(((xx // 3) + (yy // 3)) % 2 == 0, 230, 25).astype(np.uint8)
+        img[rng.random((h, w)) < 0.02] = 128
+    g = S.ORBextractor(1500, 1.2, 8, 20, 7); c = O.Extractor(1500, 1.2, 8, 20, 7)
+    if batch == 1:
+        kps, desc = g.Extract(img)
+        _cmp_frame(O, g, c, img, kps, desc)
+    else:
+        frames = np.stack([np.roll(img, 7 * f, axis=1) for f in range(batch)])
+        g.extract_batch_dev(torch.from_numpy(frames).cuda(), batch, w, h)
+        kps, desc, n = g.fetch_results(batch)
+        for f in (0, batch - 1):
+            _cmp_frame(O, g, c, frames[f], kps[f, :n[f]], desc[f, :n[f]])
+        img = frames[0]; c.extract(img)
+        g.Extract(img)
+    for l in range(8):
+        xs, ys, rs = g.debug_candidates(l)
+        cx, cy, cr = c.level_candidates(l)
+        assert np.array_equal(xs, cx.astype(np.int32)) and np.array_equal(ys, cy.astype(np.int32)) and np.array_equal(rs, cr.astype(np.int32)), l
+    if kind == "uniform":
+        assert len(c.level_candidates(0)[0]) > 0.02 * w * h          # the image really is corner-dense
+    g.close()
