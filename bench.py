@@ -560,11 +560,12 @@ def main():
     for _ in range(max(args.warmup, S)):        # every pair allocates on its first step
         step()
     sync_all()
-    # one more untimed step, alone on the GPU, with event pairs around every kernel: finds the kernel with the largest
+    # five more untimed steps, one at a time, with event pairs around every kernel: finds the kernel with the largest
     # share of GPU time
     profiling(True)
     inflight[0] = 1
-    step()
+    for _ in range(5):
+        step()
     sync_all()
     inflight[0] = S
     wt = kernel_times()

@@ -349,44 +349,68 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Short-round form (quotas up to MAXA - 3 with MAXA = 64 * NPL nodes): the same array formulation, but a round costs two
-// workgroup barriers instead of ~15.  Everything about NODES (who is expandable, the split prefix, child numbering, the new
-// node list) is done by wave 0 alone with wave-wide scans -- lane l owns list positions NPL*l .. NPL*l + NPL-1 --, and
-// everything about KEYS (relabelling to the new node, counting into the new node's quadrants for the NEXT round) is one fused
-// pass of all waves, with the quadrant counters double-buffered:
-//     [all waves]  relabel keys (round r-1), count quadrants of the new nodes into cc[r & 1]          -- barrier
-//     [wave 0]     node phase of round r: reads cc[r & 1], writes child indices into it, new list, clears cc[(r+1) & 1]
-//                                                                                                     -- barrier
-// Only a round in the largest-first regime (src/Feature.cpp:707-765, normally the last one) adds two barriers: its ordering
-// (size descending, then list position ascending) is a rank count done by all threads.
+// Short-round form for quotas up to 253 (MAXA = 256 list positions = 256 threads, one node per thread): the same array
+// formulation with a round structure of 3 workgroup barriers instead of ~15.
+//   * everything a round has to know about the NODES -- who is expandable, how many children come before a node, where the
+//     survivors go, the new list size -- falls out of ONE packed block scan (expandable | children << 10 | survivor << 21:
+//     wave scan in DPP, one barrier to exchange the four wave totals); every thread derives the round's decisions from the
+//     scan totals itself, so no flags travel through LDS;
+//   * everything about the KEYS is one fused, straight-line pass: move the key to its new node and count it into that node's
+//     quadrants for the NEXT round, with the quadrant counters double-buffered (a thread's 8 keys overlap their LDS round trips);
+//   * only the round in the largest-first regime (src/Feature.cpp:707-765, normally the last one) needs more: its order
+//     (size descending, then list position ascending) is a rank count, and the split prefix a second scan.
 // The creation sequence numbers of the long form are not needed: the list is always in reverse creation order (children
 // newest first in front of the survivors), so "latest created first" among equal sizes IS "smaller list position first".
-template <int NPL>
-__device__ __forceinline__ int wave_excl_scan(int v, int& total)
+// The first 2048 keys of a level live in LDS / registers (value, order key); HBM scratch is only touched beyond that.
+__device__ __forceinline__ int wave_incl_scan_dpp(int v)
 {
     int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)(threadIdx.x & 63) >= o) incl += t; }
-    total = __shfl(incl, 63);
-    return incl - v;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);      // row_shr 1, 2, 4, 8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);     // row_bcast 15, 31
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
+    return incl;
 }
 
-struct QtsShared { int n, Lsize, nExpand, careful, done, nE, nsplit, nc; };
-
-template <int MAXA, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_quadtree_short(QtArgs a)
+// exclusive scan over a workgroup of NW waves with ONE barrier; slot: NW ints not touched by the three scans before it
+template <int NW>
+__device__ __forceinline__ int block_excl_scan1(int v, int* slot, int& total)
 {
-    constexpr int NPL = MAXA / 64;                 // nodes per lane of wave 0
-    constexpr int KPT = kQtRegKeys;                // keys per thread kept in registers
-    __shared__ uint2 rect[2][MAXA];
-    __shared__ int cnt[2][MAXA];
-    __shared__ __attribute__((aligned(16))) int cc[2][4 * MAXA];          // quadrant counts, then child list positions, per node
-    __shared__ int remap[MAXA];
-    __shared__ unsigned long long skeys[MAXA];
+    const int incl = wave_incl_scan_dpp(v);
+    if ((threadIdx.x & 63) == 63) slot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = 0; total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const int t = slot[w]; if (w < (int)(threadIdx.x >> 6)) base += t; total += t; }
+    return base + incl - v;
+}
+
+#ifdef SSVIO_QT_TIMING
+__device__ unsigned long long g_qtTimes[64];
+#define QT_STAMP(K) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_qtTimes[K] = wall_clock64(); } while (0)
+extern "C" int ssvio_debug_qt_times(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qtTimes), sizeof(g_qtTimes)); }
+#else
+#define QT_STAMP(K) do { } while (0)
+#endif
+
+template <int MAXA>
+__global__ __launch_bounds__(MAXA) void k_quadtree_short(QtArgs a)
+{
+    constexpr int THREADS = MAXA, NW = THREADS / 64;
+    constexpr int KPT = kQtRegKeys;                // keys per thread kept in registers (and LDS)
+    __shared__ __attribute__((aligned(16))) uint4 rec[2][MAXA];           // node record: {x0 | y0 << 16, x1 | y1 << 16, keys in the node, -}
+    __shared__ int rootCnt0[kMaxRoots];
+    __shared__ __attribute__((aligned(16))) uint4 rootTab[kMaxRoots];     // per root: {rectangle, keys, list position}
+    __shared__ __attribute__((aligned(16))) int cc[2][4 * MAXA + 64];     // quadrant counts, then child list positions, per node; the last
+                                                                          // 64 ints: where the counting atomics of keys that count nowhere land
+    __shared__ __attribute__((aligned(16))) unsigned long long skeys[MAXA];   // the largest-first round's 32-bit sort keys; best key per node at the end
     __shared__ int ord2[MAXA];
     __shared__ unsigned char split[MAXA];
-    __shared__ unsigned long long best[MAXA];
-    __shared__ QtsShared sh;
+    __shared__ uint32_t lval[KPT * THREADS], lord[KPT * THREADS];          // the level's first keys: value, order key
+    __shared__ int slots[4][NW];
+    __shared__ int shN, shExp[2], shNc;
 
     const int tid = threadIdx.x, lane = tid & 63;
     int frame, level;
@@ -403,278 +427,296 @@ __global__ __launch_bounds__(THREADS) void k_quadtree_short(QtArgs a)
     int* selCount = a.selCount + frame * kMaxLevels + level;
     uint2* sel = a.sel + (size_t)frame * a.selPerFrame + L.selBase;
 
-    if (tid == 0) { sh.n = 0; sh.nExpand = 0; sh.careful = 0; sh.done = 0; }
-    for (int i = tid; i < MAXA; i += THREADS) { cnt[0][i] = 0; }
-    for (int i = tid; i < 4 * MAXA; i += THREADS) { cc[0][i] = 0; }
+    QT_STAMP(0);
+    if (tid == 0) { shN = 0; shExp[0] = 0; shExp[1] = 0; }
+    if (tid < kMaxRoots) rootCnt0[tid] = 0;
+    *(int4*)&cc[0][4 * tid] = make_int4(0, 0, 0, 0);
     __syncthreads();
-    // ---- 0. resolve the per-cell threshold fallback, gather the used entries (value to kval, order key to kord)
-    for (int i0 = 0; i0 < nraw; i0 += THREADS) {
-        const int i = i0 + tid;
-        bool use = false; uint2 e = make_uint2(0, 0);
-        if (i < nraw) {
-            e = raw[i];
-            const int cell = (e.x >> 12) & 0x3FFFF, flags = e.x >> 30;
-            use = cellIni[cell] ? (flags & 1) : (flags & 2);
+    // ---- 0. resolve the per-cell threshold fallback, gather the used entries.  A thread's KPT entries (and then their cells' flags)
+    // are requested together: one round trip to L2 per 2048 entries, and one LDS reservation per wave
+    for (int i0 = 0; i0 < nraw; i0 += KPT * THREADS) {
+        uint2 e[KPT]; int ini[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) { const int i = i0 + tid + j * THREADS; e[j] = i < nraw ? raw[i] : make_uint2(0, 0); }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) { const int i = i0 + tid + j * THREADS; ini[j] = i < nraw ? cellIni[(e[j].x >> 12) & 0x3FFFF] : 0; }
+        unsigned useMask = 0;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int i = i0 + tid + j * THREADS;
+            const int flags = e[j].x >> 30;
+            if (i < nraw && (ini[j] ? (flags & 1) : (flags & 2))) useMask |= 1u << j;
         }
-        const unsigned long long m = __ballot(use);
-        if (m) {
+        const int mine = __popc(useMask);
+        const int incl = wave_incl_scan_dpp(mine);
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        if (tot) {
             int base = 0;
-            if (lane == 0) base = atomicAdd(&sh.n, __popcll(m));
-            base = __shfl(base, 0);
-            if (use) {
-                const int pos = base + __popcll(m & ((1ull << lane) - 1));
-                kval[pos] = e.y; kord[pos] = e.x & 0x3FFFFFFFu;
+            if (lane == 63) base = atomicAdd(&shN, tot);
+            int pos = __builtin_amdgcn_readlane(base, 63) + incl - mine;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                if (useMask & (1u << j)) {
+                    if (pos < KPT * THREADS) { lval[pos] = e[j].y; lord[pos] = e[j].x & 0x3FFFFFFFu; }
+                    else { kval[pos] = e[j].y; kord[pos] = e[j].x & 0x3FFFFFFFu; }
+                    ++pos;
+                }
             }
         }
     }
     __syncthreads();
-    const int n = sh.n;
+    QT_STAMP(1);
+    const int n = shN;
     if (n == 0) { if (tid == 0) *selCount = 0; return; }
-    uint32_t rv[KPT]; int rn[KPT];
+    uint32_t rv[KPT]; int rn[KPT]; uint2 rr[KPT];            // per key: value, list position of its node, that node's rectangle
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) { const int k = tid + j * THREADS; rv[j] = k < n ? kval[k] : 0u; rn[j] = 0; }
-    const int nReg = min(n, KPT * THREADS);                  // keys [nReg, n) use kval / knode in HBM
+    for (int j = 0; j < KPT; ++j) { const int k = tid + j * THREADS; rv[j] = k < n ? lval[k] : 0u; rn[j] = 0; }
+    const int nReg = min(n, KPT * THREADS);                  // keys [nReg, n) use kval / kord / knode in HBM
 
     // ---- 1. roots (:574-619)
     const int nIni = L.nIni;
     const float hX = L.hX;
+    if (nIni > 1) {
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        if (tid + j * THREADS < n) {
-            int b = (int)((float)(rv[j] & 0xFFF) / hX);          // vpInitNodes[kp.pt.x / hX], :599
+        for (int j = 0; j < KPT; ++j) {
+            const int b = (int)((float)(rv[j] & 0xFFF) / hX);    // vpInitNodes[kp.pt.x / hX], :599
+            rn[j] = tid + j * THREADS < n ? min(max(b, 0), nIni - 1) : -1;
+        }
+        for (int b = 0; b < nIni; ++b) {                         // one LDS add per wave and root
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) c += rn[j] == b ? 1 : 0;
+            const int w = wave_incl_scan_dpp(c);
+            if (lane == 63 && w) atomicAdd(&rootCnt0[b], w);
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) rn[j] = max(rn[j], 0);
+        for (int k = nReg + tid; k < n; k += THREADS) {
+            int b = (int)((float)(kval[k] & 0xFFF) / hX);
             b = min(max(b, 0), nIni - 1);
-            rn[j] = b;
-            atomicAdd(&cnt[0][b], 1);
+            knode[k] = b;
+            atomicAdd(&rootCnt0[b], 1);
         }
+        __syncthreads();
+    } else {                                                     // one root (every 4:3 image): all keys are its keys
+        for (int k = nReg + tid; k < n; k += THREADS) knode[k] = 0;
     }
-    for (int k = nReg + tid; k < n; k += THREADS) {
-        int b = (int)((float)(kval[k] & 0xFFF) / hX);
-        b = min(max(b, 0), nIni - 1);
-        knode[k] = b;
-        atomicAdd(&cnt[0][b], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int m = 0;
-        for (int i = 0; i < nIni; ++i) {
-            if (cnt[0][i] > 0) {                                  // empty roots are erased (:611-614)
-                const int c = cnt[0][i];
-                rect[0][m] = make_uint2((uint32_t)L.rootX[i] | 0u << 16, (uint32_t)L.rootX[i + 1] | (uint32_t)H << 16);
-                remap[i] = m; cnt[0][m] = c; ++m;
-            } else remap[i] = 0;
+    // empty roots are erased (:611-614): thread i < nIni places root i (its list position = the number of non-empty roots before it)
+    int Lsize = 0;
+    {
+        int myPos = 0, myCnt = 0;
+#pragma unroll
+        for (int i = 0; i < kMaxRoots; ++i) {
+            const int c = __builtin_amdgcn_readfirstlane(nIni > 1 ? (i < nIni ? rootCnt0[i] : 0) : (i == 0 ? n : 0));     // uniform
+            if (tid == i) { myPos = Lsize; myCnt = c; }
+            if (c > 0) ++Lsize;
         }
-        sh.Lsize = m;
+        if (tid < nIni) {
+            const uint4 r4 = make_uint4((uint32_t)L.rootX[tid] | 0u << 16, (uint32_t)L.rootX[tid + 1] | (uint32_t)H << 16, (uint32_t)myCnt, 0u);
+            rootTab[tid] = make_uint4(r4.x, r4.y, r4.z, (uint32_t)myPos);
+            if (myCnt > 0) rec[0][myPos] = r4;
+        }
+        if (nIni > 1) __syncthreads();                           // (with one root every thread already knows it all)
     }
-    __syncthreads();
-    // keys move to their root's list position and are counted into its quadrants: the first round's counts
     auto quadrant = [](const uint2 r, uint32_t v) -> int {
         const int x = v & 0xFFF, y = (v >> 12) & 0xFFF;
         const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
         const int hx = x0 + ((x1 - x0 + 1) >> 1), hy = y0 + ((y1 - y0 + 1) >> 1);   // ceil(d / 2), :21-22
         return (x < hx ? 0 : 1) + (y < hy ? 0 : 2);
     };
+    const int sink = 4 * MAXA + lane;                            // a cell of cc[] that belongs to no node
+    // keys move to their root's list position and are counted into its quadrants: the first round's counts
     {
-        auto first = [&](int root, uint32_t v) -> int {
-            const int nn = remap[root];
-            if (cnt[0][nn] >= 2) atomicAdd(&cc[0][4 * nn + quadrant(rect[0][nn], v)], 1);
+        const uint4 root0 = make_uint4((uint32_t)L.rootX[0] | 0u << 16, (uint32_t)L.rootX[1] | (uint32_t)H << 16, (uint32_t)n, 0u);
+        auto first = [&](int root, uint32_t v, bool live, uint2& rct) -> int {
+            const uint4 r4 = nIni > 1 ? rootTab[root] : root0;   // {rectangle, keys, list position}
+            const int nn = (int)r4.w;
+            rct = make_uint2(r4.x, r4.y);
+            const bool counts = live && r4.z >= 2;
+            atomicAdd(&cc[0][counts ? 4 * nn + quadrant(rct, v) : sink], 1);
             return nn;
         };
+        {
+            uint4 r8[KPT]; int dst8[KPT];
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) if (tid + j * THREADS < n) rn[j] = first(rn[j], rv[j]);
-        for (int k = nReg + tid; k < n; k += THREADS) knode[k] = first(knode[k], kval[k]);
+            for (int j = 0; j < KPT; ++j) r8[j] = nIni > 1 ? rootTab[rn[j]] : root0;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const bool live = tid + j * THREADS < n;
+                rr[j] = make_uint2(r8[j].x, r8[j].y);
+                dst8[j] = (live && r8[j].z >= 2) ? 4 * (int)r8[j].w + quadrant(rr[j], rv[j]) : sink;
+                rn[j] = live ? (int)r8[j].w : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) atomicAdd(&cc[0][dst8[j]], 1);
+        }
+        uint2 dummyRect;
+        for (int k = nReg + tid; k < n; k += THREADS) knode[k] = first(knode[k], kval[k], true, dummyRect);
     }
     __syncthreads();
 
-    // ---- 2. rounds.  The list size and the regime of a round are read from LDS BEFORE the barrier that ends the previous round:
-    // wave 0 rewrites them in its node phase, which no barrier separates from the top of the round.
-    int cur = 0;
-    int Lsize = sh.Lsize;
+    // ---- 2. rounds
+    QT_STAMP(2);
+    int cur = 0, scanNo = 0;
     bool careful = false;
-    __syncthreads();
     for (int round = 0; round < 64; ++round) {
-        uint2* R = rect[cur]; int* C = cnt[cur]; int* CC = cc[cur];
-        uint2* R2 = rect[cur ^ 1]; int* C2 = cnt[cur ^ 1]; int* CC2 = cc[cur ^ 1];
-        // ---- node phase, part 1 (wave 0): expandable nodes; in the largest-first regime their sort keys
-        int myE[NPL], myQ[NPL];
-        int eBase = 0, nE = 0;
-        if (tid < 64) {
-            int nMine = 0;
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                const int i = lane * NPL + j;
-                myE[j] = 0; myQ[j] = 0;
-                if (i < Lsize && C[i] >= 2) {
-                    const int4 q = *(const int4*)&CC[4 * i];
-                    myE[j] = 1; myQ[j] = (q.x > 0) + (q.y > 0) + (q.z > 0) + (q.w > 0);
-                    ++nMine;
-                }
-            }
-            eBase = wave_excl_scan<NPL>(nMine, nE);
-            if (careful) {
-                int t = eBase;
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) if (myE[j]) { const int i = lane * NPL + j; skeys[t++] = ((unsigned long long)(uint32_t)C[i] << 12) | (unsigned long long)(MAXA - 1 - i); }
-            }
-            if (lane == 0) { sh.nE = nE; if (nE == 0) sh.done = 1; }
-        }
-        if (careful) {
-            // largest first, ties: latest created (= smaller list position) first (= ascending sort() walked from the back, :716-717)
+        QT_STAMP(3 + 2 * round);
+        const uint4* REC = rec[cur]; int* CC = cc[cur];
+        uint4* REC2 = rec[cur ^ 1]; int* CC2 = cc[cur ^ 1];
+        const int i = tid;                                          // my list position
+        const uint4 myRec = REC[i];
+        const int myC = i < Lsize ? (int)myRec.z : 0;
+        const bool e = myC >= 2;                                    // expandable
+        const int4 q4 = *(const int4*)&CC[4 * i];
+        const int q = e ? (q4.x > 0) + (q4.y > 0) + (q4.z > 0) + (q4.w > 0) : 0;
+        if (tid == 0) shExp[(round + 1) & 1] = 0;
+        int nE, nc, nsurv, sBase, dq = 0, node = -1;                // node: the node whose children I create (dq children come before them)
+        int4 nq4 = q4;
+        if (!careful) {
+            // all expandable nodes are split, in list order
+            int tot;
+            const int ex = block_excl_scan1<NW>((e ? 1 : 0) | (q << 10) | ((i < Lsize && !e) ? 1 << 21 : 0), slots[scanNo++ & 3], tot);
+            nE = tot & 1023; nc = (tot >> 10) & 2047; nsurv = tot >> 21;
+            if (nE == 0) break;                                     // nothing to divide: the list stays as it is (:703)
+            dq = (ex >> 10) & 2047; sBase = ex >> 21;
+            split[i] = e ? 1 : 0;
+            if (e) node = i;
+        } else {
+            int tot;
+            const int eBase = block_excl_scan1<NW>(e ? 1 : 0, slots[scanNo++ & 3], nE);
+            if (nE == 0) break;
+            // largest first, ties: latest created (= smaller list position) first (= ascending sort() walked from the back, :716-717).
+            // 32-bit keys: a node holds fewer than 2^24 keys (a level has at most 4128^2 / 4 candidates).
+            uint32_t* sk = (uint32_t*)skeys;
+            if (e) sk[eBase] = ((uint32_t)myC << 8) | (uint32_t)(MAXA - 1 - i);
+            if (tid >= nE && tid < ((nE + 3) & ~3)) sk[tid] = 0;     // pad the last group of four
+            split[i] = 0;
             __syncthreads();
-            const int nEs = sh.nE;
-            for (int e = tid; e < nEs; e += THREADS) {
-                const unsigned long long me = skeys[e];
+            if (tid < nE) {
+                const uint32_t me = sk[tid];
                 int rank = 0;
-                for (int u = 0; u < nEs; ++u) rank += skeys[u] > me ? 1 : 0;
-                ord2[rank] = MAXA - 1 - (int)(me & 0xFFF);
+                for (int u = 0; u < nE; u += 4) {
+                    const uint4 k4 = *(const uint4*)&sk[u];
+                    rank += (k4.x > me) + (k4.y > me) + (k4.z > me) + (k4.w > me);
+                }
+                ord2[rank] = MAXA - 1 - (int)(me & 0xFF);
             }
             __syncthreads();
+            int qd = 0;
+            if (tid < nE) {
+                node = ord2[tid];
+                nq4 = *(const int4*)&CC[4 * node];
+                qd = (nq4.x > 0) + (nq4.y > 0) + (nq4.z > 0) + (nq4.w > 0);
+            }
+            const int run = block_excl_scan1<NW>(tid < nE ? qd - 1 : 0, slots[scanNo++ & 3], tot);    // (children - 1) before me in the order
+            dq = run + tid;                                          // children created before order[tid]
+            // the split prefix ends with the first node that brings the list to N (:762).  Every node adds >= 0, so position tid is
+            // split iff the nodes before it have not reached N yet, and it is the last one iff it does (or the order ends with it)
+            const bool mineSplit = tid < nE && (tid == 0 || Lsize + run < N);
+            if (mineSplit) { split[node] = 1; if (tid == nE - 1 || Lsize + run + qd - 1 >= N) shNc = dq + qd; }      // children in total
+            else node = -1;
+            __syncthreads();
+            nc = shNc;
+            sBase = block_excl_scan1<NW>((i < Lsize && !split[i]) ? 1 : 0, slots[scanNo++ & 3], nsurv);
         }
-        // ---- node phase, part 2 (wave 0): the split prefix, child numbering, the new list
-        if (tid < 64 && nE > 0) {
-            int nd[NPL], dq[NPL];             // node at my positions of the split order, its number of children
-            int nsplit = nE, nc;
-            if (!careful) {
-                // all expandable nodes, in list order: position t = eBase + (ordinal among my nodes)
-                int myC = 0;
+        // survivors keep their relative order behind the new children
+        // (a survivor's four quadrant cells all name its new position: the key pass looks a key's next node up in one place)
+        if (i < Lsize && !split[i]) { const int idx = nc + sBase; REC2[idx] = myRec; *(int4*)&CC[4 * i] = make_int4(idx, idx, idx, idx); }
+        // children, pushed to the front one by one (n1..n4, :655-694) => reverse creation order
+        int myExpand = 0;
+        if (node >= 0) {
+            const uint4 r = REC[node];
+            const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
+            const int hx = x0 + ((x1 - x0 + 1) >> 1), hy = y0 + ((y1 - y0 + 1) >> 1);
+            int m = dq;
+            int qq[4] = {nq4.x, nq4.y, nq4.z, nq4.w};
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) myC += myQ[j];
-                int totC;
-                int cBase = wave_excl_scan<NPL>(myC, totC);
-                nc = totC;
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    const int i = lane * NPL + j;
-                    nd[j] = myE[j] ? i : -1; dq[j] = cBase;          // dq = children created before this node
-                    cBase += myQ[j];
-                    if (i < MAXA) split[i] = (unsigned char)myE[j];
-                }
-            } else {
-                int myD = 0, q4[NPL];
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    const int t = lane * NPL + j;
-                    nd[j] = -1; q4[j] = 0;
-                    if (t < nE) {
-                        nd[j] = ord2[t];
-                        const int4 q = *(const int4*)&CC[4 * nd[j]];
-                        q4[j] = (q.x > 0) + (q.y > 0) + (q.z > 0) + (q.w > 0);
-                        myD += q4[j] - 1;
-                    }
-                }
-                int totD;
-                int run = wave_excl_scan<NPL>(myD, totD);          // exclusive sum of (children - 1) over the order
-                int cut = 1 << 30;
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    const int t = lane * NPL + j;
-                    dq[j] = run + t;                                // children created before order[t]
-                    if (t < nE) { run += q4[j] - 1; if (Lsize + run >= N) cut = min(cut, t); }     // :762
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) cut = min(cut, __shfl_xor(cut, o));
-                nsplit = min(cut, nE - 1) + 1;
-                // children in total = those before order[nsplit-1] plus its own
-                int last = 0;
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) if (lane * NPL + j == nsplit - 1) last = dq[j] + q4[j];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
-                nc = last;
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) { const int i = lane * NPL + j; if (i < MAXA) split[i] = 0; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) { const int t = lane * NPL + j; if (t < nsplit) split[nd[j]] = 1; else nd[j] = -1; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-            }
-            // survivors keep their relative order behind the new children
-            int mySurv = 0, surv[NPL];
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) { const int i = lane * NPL + j; surv[j] = (i < Lsize && !split[i]) ? 1 : 0; mySurv += surv[j]; }
-            int nsurv;
-            int sBase = wave_excl_scan<NPL>(mySurv, nsurv);
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                const int i = lane * NPL + j;
-                if (surv[j]) { const int idx = nc + sBase++; R2[idx] = R[i]; C2[idx] = C[i]; remap[i] = idx; }
-            }
-            // children, pushed to the front one by one (n1..n4, :655-694) => reverse creation order
-            int myExpand = 0;
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                if (nd[j] >= 0) {
-                    const int node = nd[j];
-                    const uint2 r = R[node];
-                    const int x0 = r.x & 0xFFFF, y0 = r.x >> 16, x1 = r.y & 0xFFFF, y1 = r.y >> 16;
-                    const int hx = x0 + ((x1 - x0 + 1) >> 1), hy = y0 + ((y1 - y0 + 1) >> 1);
-                    int m = dq[j];
-                    int4 q = *(const int4*)&CC[4 * node];
-                    int qq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int c = qq[k];
-                        if (c > 0) {
-                            const int idx = nc - 1 - m;
-                            const int cx0 = (k & 1) ? hx : x0, cx1 = (k & 1) ? x1 : hx, cy0 = (k & 2) ? hy : y0, cy1 = (k & 2) ? y1 : hy;
-                            R2[idx] = make_uint2((uint32_t)cx0 | (uint32_t)cy0 << 16, (uint32_t)cx1 | (uint32_t)cy1 << 16);
-                            C2[idx] = c;
-                            qq[k] = idx;                              // child position for the key relabelling
-                            if (c > 1) ++myExpand;
-                            ++m;
-                        }
-                    }
-                    *(int4*)&CC[4 * node] = make_int4(qq[0], qq[1], qq[2], qq[3]);
+            for (int k = 0; k < 4; ++k) {
+                const int c = qq[k];
+                if (c > 0) {
+                    const int idx = nc - 1 - m;
+                    const int cx0 = (k & 1) ? hx : x0, cx1 = (k & 1) ? x1 : hx, cy0 = (k & 2) ? hy : y0, cy1 = (k & 2) ? y1 : hy;
+                    REC2[idx] = make_uint4((uint32_t)cx0 | (uint32_t)cy0 << 16, (uint32_t)cx1 | (uint32_t)cy1 << 16, (uint32_t)c, 0u);
+                    qq[k] = idx;                                  // child position for the key relabelling
+                    if (c > 1) ++myExpand;
+                    ++m;
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) myExpand += __shfl_xor(myExpand, o);
-            const int newSize = nc + nsurv;
-            // the next round's quadrant counters
-            for (int i = lane; i < newSize; i += 64) *(int4*)&CC2[4 * i] = make_int4(0, 0, 0, 0);
-            if (lane == 0) {
-                sh.Lsize = newSize;
-                if (newSize >= N || newSize == Lsize) sh.done = 1;                       // :703 / :769
-                if (!careful && newSize + 3 * myExpand > N) sh.careful = 1;              // :707
-            }
+            *(int4*)&CC[4 * node] = make_int4(qq[0], qq[1], qq[2], qq[3]);
         }
-        __syncthreads();
-        if (sh.nE == 0) break;                                     // nothing to divide: the list stays as it is
-        // ---- key phase (all waves): move every key to its new node; unless this was the last round, count it there
-        const bool last = sh.done != 0;
-        Lsize = sh.Lsize; careful = sh.careful != 0;               // the next round's, stable until its node phase
         {
-            auto relabel = [&](int pn, uint32_t v) -> int {
-                const int nn = split[pn] ? CC[4 * pn + quadrant(R[pn], v)] : remap[pn];
-                if (!last && C2[nn] >= 2) atomicAdd(&CC2[4 * nn + quadrant(R2[nn], v)], 1);
+            const int w = wave_incl_scan_dpp(myExpand);
+            if (lane == 63 && w) atomicAdd(&shExp[round & 1], w);
+        }
+        const int newSize = nc + nsurv;
+        if (i < newSize) *(int4*)&CC2[4 * i] = make_int4(0, 0, 0, 0);       // the next round's quadrant counters
+        __syncthreads();
+        QT_STAMP(4 + 2 * round);
+        const int nToExpand = shExp[round & 1];
+        const bool last = newSize >= N || newSize == Lsize;                 // :703 / :769
+        // ---- key phase: move every key to its new node; unless this was the last round, count it there.  Straight-line code (keys
+        // beyond n walk node 0 and count into a sink cell): the dependent LDS reads of a thread's 8 keys overlap instead of queueing
+        {
+            // a key knows its node's rectangle (registers): one read for the next node, one for that node's record, one count
+            auto relabel = [&](int pn, uint32_t v, bool live, uint2& rct) -> int {
+                const int nn = CC[4 * pn + quadrant(rct, v)];
+                const uint4 r4 = REC2[nn];
+                rct = make_uint2(r4.x, r4.y);
+                const bool counts = live && !last && r4.z >= 2;
+                atomicAdd(&CC2[counts ? 4 * nn + quadrant(rct, v) : sink], 1);
                 return nn;
             };
+            // the register keys in stages, so that the 8 look-ups of a stage are in flight together (written as one call per key the
+            // compiler waits for every LDS answer before it asks the next question: 16 round trips in a row, 1.5 us per pass)
+            int nn8[KPT]; uint4 r8[KPT]; int dst8[KPT];
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) if (tid + j * THREADS < n) rn[j] = relabel(rn[j], rv[j]);
-            for (int k = nReg + tid; k < n; k += THREADS) knode[k] = relabel(knode[k], kval[k]);
+            for (int j = 0; j < KPT; ++j) nn8[j] = CC[4 * rn[j] + quadrant(rr[j], rv[j])];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) r8[j] = REC2[nn8[j]];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const bool live = tid + j * THREADS < n;
+                rr[j] = make_uint2(r8[j].x, r8[j].y);
+                const int cell = 4 * nn8[j] + quadrant(rr[j], rv[j]);
+                dst8[j] = (live && !last && r8[j].z >= 2) ? cell : sink;
+                rn[j] = live ? nn8[j] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) atomicAdd(&CC2[dst8[j]], 1);
+            for (int k = nReg + tid; k < n; k += THREADS) {
+                const int pn = knode[k];
+                const uint4 p4 = REC[pn];
+                uint2 rct = make_uint2(p4.x, p4.y);
+                knode[k] = relabel(pn, kval[k], true, rct);
+            }
         }
         cur ^= 1;
+        Lsize = newSize;
+        if (!careful && newSize + 3 * nToExpand > N) careful = true;        // :707
         __syncthreads();
         if (last) break;
     }
 
     // ---- 3. best key of every node (:778-796): largest response, then first in input order
-    const int Lfin = sh.Lsize;
-    for (int i = tid; i < Lfin; i += THREADS) best[i] = 0;
+    QT_STAMP(40);
+    unsigned long long* best = skeys;
+    best[tid] = 0;
     __syncthreads();
-    auto offer = [&](int node, uint32_t v, uint32_t o) {
+    auto offer = [&](int nd, uint32_t v, uint32_t o) {
         const unsigned long long key = ((unsigned long long)(v >> 24) << 56) | ((unsigned long long)(0x3FFFFFFFu - o) << 24) | (v & 0xFFFFFFu);
-        atomicMax(&best[node], key);
+        atomicMax(&best[nd], key);
     };
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) { const int k = tid + j * THREADS; if (k < n) offer(rn[j], rv[j], kord[k]); }
+    for (int j = 0; j < KPT; ++j) { const int k = tid + j * THREADS; if (k < n) offer(rn[j], rv[j], lord[k]); }
     for (int k = nReg + tid; k < n; k += THREADS) offer(knode[k], kval[k], kord[k]);
     __syncthreads();
-    for (int i = tid; i < Lfin; i += THREADS) {
-        const unsigned long long b = best[i];
+    if (tid < Lsize) {
+        const unsigned long long b = best[tid];
         const uint32_t x = ((uint32_t)b & 0xFFF) + kMinBorder, y = (((uint32_t)b >> 12) & 0xFFF) + kMinBorder;   // :905-906
-        sel[i] = make_uint2(x | (y << 16), (uint32_t)level | ((uint32_t)(b >> 56) << 8));
+        sel[tid] = make_uint2(x | (y << 16), (uint32_t)level | ((uint32_t)(b >> 56) << 8));
     }
-    if (tid == 0) *selCount = Lfin;
+    if (tid == 0) *selCount = Lsize;
+    QT_STAMP(41);
 }
 
 size_t quadtree_lds_bytes(int maxa)
@@ -703,7 +745,7 @@ int launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipSt
     // the smallest node capacity that holds quota + 3: 19 KB of LDS at 256 nodes (73 KB at 1024), so that the workgroups of
     // other kernels (k_fast, k_describe of the step in flight beside this one) still fit on the CU
     static const bool longForm = getenv("SSVIO_QUADTREE_LONG") != nullptr;      // measuring knob: the round structure with ~15 barriers
-    if (!longForm && maxAlive <= 256) hipLaunchKernelGGL((k_quadtree_short<256, 256>), dim3(nlevels * batch), dim3(256), 0, s, a);
+    if (!longForm && maxAlive <= 256) hipLaunchKernelGGL((k_quadtree_short<256>), dim3(nlevels * batch), dim3(256), 0, s, a);
     else if (maxAlive <= 256) hipLaunchKernelGGL((k_quadtree<256, false>), dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(256), s, a);
     else if (maxAlive <= 1024) hipLaunchKernelGGL((k_quadtree<1024, false>), dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(1024), s, a);
     else if (maxAlive <= 2048) hipLaunchKernelGGL((k_quadtree<2048, false>), dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(2048), s, a);
