@@ -14,19 +14,22 @@ int upload_rows(uint8_t* dst, const uint8_t* src, int n, int stride, std::vector
     return SSVIO_OK;
 }
 
-// choose how many pieces the train set is cut into so that the launch has >= ~2048 workgroups (two per SIMD)
+// Choose how many pieces the train set is cut into.  Target: ~2048 workgroups (8 waves per SIMD) of at least 64 train rows each, so
+// that every SIMD ends up with the same number of waves.  The kernel splits the rows a set really holds evenly over the chunks, so
+// the chunk count -- not the chunk size -- is what this fixes; chunkRows is the upper bound for the partial lists' layout.
+// Query rows: a set handed over by the extractor holds up to 32 rows less than it can (the quadtree's overshoot slack); counting
+// query blocks without that slack keeps a block that will be empty out of the balance.
 static void pick_chunks(int maxQ, int maxT, int npairs, int& nChunks, int& chunkRows)
 {
     static const int forcedRows = [] { const char* e = getenv("SSVIO_MATCH_CHUNKROWS"); return e ? atoi(e) : 0; }();   // tuning knob
-    const int R = knn2_queries_per_lane(maxQ);
-    const long qBlocks = (long)((maxQ + 256 * R - 1) / (256 * R)) * npairs;
-    long want = (2048 + qBlocks - 1) / qBlocks;
-    const long maxChunks = std::max(1, (maxT + 127) / 128);
+    static const int target = [] { const char* e = getenv("SSVIO_MATCH_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+    const long qBlocks = (long)knn2_query_blocks(maxQ) * npairs;
+    long want = (target + qBlocks / 2) / qBlocks;
+    const long maxChunks = std::max(1, (maxT + 63) / 64);
     want = std::min<long>(std::min<long>(want, maxChunks), 64);
     nChunks = (int)std::max<long>(want, 1);
-    chunkRows = ((maxT + nChunks - 1) / nChunks + 127) / 128 * 128;
-    if (forcedRows >= 128) chunkRows = forcedRows / 128 * 128;
-    nChunks = std::max(1, (maxT + chunkRows - 1) / chunkRows);
+    chunkRows = ((maxT + nChunks - 1) / nChunks + 7) / 8 * 8;
+    if (forcedRows >= 8) { chunkRows = forcedRows / 8 * 8; nChunks = std::max(1, (maxT + chunkRows - 1) / chunkRows); }
 }
 
 // the pair list of the batched entry points, on the device (an unchanged list is not uploaded again)
@@ -65,7 +68,7 @@ int match_plan(int maxQ, int maxT, int npairs, int mode, size_t limitEntries, Ma
         auto fit = [&](int& nChunks, int& chunkRows, int rowsT) {
             if ((size_t)nChunks * per <= lim) return;
             const int want = (int)(lim / per);
-            chunkRows = ((rowsT + want - 1) / want + 127) / 128 * 128;
+            chunkRows = ((rowsT + want - 1) / want + 7) / 8 * 8;
             nChunks = std::max(1, (rowsT + chunkRows - 1) / chunkRows);
         };
         fit(p.nChunks, p.chunkRows, maxT);

@@ -8,6 +8,7 @@
 // src/FeatureMatching.cpp:85-102,211-228 with lowest-index ties.  No MFMA: the path is
 // integer xor/popcount, VALU-bound.
 #include "match.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace ssvio {
@@ -58,56 +59,71 @@ __device__ __forceinline__ void row_update(const uint32_t (&q)[R][8], uint32_t (
 template <int R>
 __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
 {
-    __shared__ uint4 tile[2][kTT * 2];                // two buffers: the next tile lands while this one is consumed
+    __shared__ uint4 tile[2][kTT * 2 + 2];            // two buffers: the next tile lands while this one is consumed (+ a row of slack: the row prefetch)
     const int tid = threadIdx.x;
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int qset = a.pairs ? a.pairs[2 * pair + a.swap] : 0;
     const int tset = a.pairs ? a.pairs[2 * pair + 1 - a.swap] : 0;
     const int nq = clamp_rows(a.qcounts[qset], a.maxRows), nt = clamp_rows(a.tcounts[tset], a.maxRows);
-    const int qtile = blockIdx.x * 256 * R;
-    if (qtile >= nq) return;                                   // block-uniform
     const uint4* Q = a.qdesc + (size_t)qset * a.qSetStrideRows * 2;
     const uint4* T = a.tdesc + (size_t)tset * a.tSetStrideRows * 2;
-    const int cBegin = chunk * a.chunkRows, cEnd = min(nt, cBegin + a.chunkRows);
-
-    uint32_t q[R][8], k1[R], k2[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int qi = qtile + r * 256 + tid;
-        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-        if (qi < nq) { lo = Q[(size_t)qi * 2]; hi = Q[(size_t)qi * 2 + 1]; }
-        q[r][0] = lo.x; q[r][1] = lo.y; q[r][2] = lo.z; q[r][3] = lo.w;
-        q[r][4] = hi.x; q[r][5] = hi.y; q[r][6] = hi.z; q[r][7] = hi.w;
-        k1[r] = kKeyInit; k2[r] = kKeyInit;
-    }
-    // train rows stream HBM/L2 -> registers -> LDS, one tile ahead of the compute
-    int buf = 0;
-    if (cBegin < cEnd) {
-        const int rows = min(kTT, cEnd - cBegin);
-        if (tid < rows * 2) tile[0][tid] = T[(size_t)cBegin * 2 + tid];
-    }
-    __syncthreads();
-    for (int t0 = cBegin; t0 < cEnd; t0 += kTT) {
-        const int rows = min(kTT, cEnd - t0);
-        const int nextRows = min(kTT, cEnd - (t0 + kTT));
-        uint4 pre = make_uint4(0, 0, 0, 0);
-        if (tid < nextRows * 2) pre = T[(size_t)(t0 + kTT) * 2 + tid];
-        const uint4* tl = tile[buf];
-        if (rows == kTT) {
-#pragma unroll 4
-            for (int j = 0; j < kTT; ++j) row_update<R>(q, k1, k2, tl[2 * j], tl[2 * j + 1], (uint32_t)(t0 + j));
-        } else {
-            for (int j = 0; j < rows; ++j) row_update<R>(q, k1, k2, tl[2 * j], tl[2 * j + 1], (uint32_t)(t0 + j));
-        }
-        if (tid < nextRows * 2) tile[buf ^ 1][tid] = pre;
-        __syncthreads();
-        buf ^= 1;
-    }
+    // the train rows a set actually holds are split evenly over the chunks (a.chunkRows is the host's upper bound, from the rows a
+    // set CAN hold): no chunk is left empty or short when the sets are not full
+    const int rowsPer = min(a.chunkRows, ((nt + a.nChunks - 1) / a.nChunks + 7) & ~7);
+    const int cBegin = chunk * rowsPer, cEnd = min(nt, cBegin + rowsPer);
     uint2* out = a.partial + ((size_t)pair * a.nChunks + chunk) * a.maxRows;
+    // The grid holds the query blocks the sets are EXPECTED to fill (launch_knn2: the extractor's sets come with up to 32 rows of
+    // slack), so that no workgroup starts only to find itself empty; a block walks on to the (rare) query rows beyond the grid.
+    for (int qtile = blockIdx.x * 256 * R; qtile < nq; qtile += gridDim.x * 256 * R) {      // block-uniform
+        uint32_t q[R][8], k1[R], k2[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int qi = qtile + r * 256 + tid;
-        if (qi < nq) out[qi] = make_uint2(k1[r], k2[r]);
+        for (int r = 0; r < R; ++r) {
+            const int qi = qtile + r * 256 + tid;
+            uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+            if (qi < nq) { lo = Q[(size_t)qi * 2]; hi = Q[(size_t)qi * 2 + 1]; }
+            q[r][0] = lo.x; q[r][1] = lo.y; q[r][2] = lo.z; q[r][3] = lo.w;
+            q[r][4] = hi.x; q[r][5] = hi.y; q[r][6] = hi.z; q[r][7] = hi.w;
+            k1[r] = kKeyInit; k2[r] = kKeyInit;
+        }
+        // train rows stream HBM/L2 -> registers -> LDS, one tile ahead of the compute
+        int buf = 0;
+        __syncthreads();                                          // (a second query tile: the previous one is done with the buffers)
+        if (cBegin < cEnd) {
+            const int rows = min(kTT, cEnd - cBegin);
+            if (tid < rows * 2) tile[0][tid] = T[(size_t)cBegin * 2 + tid];
+        }
+        __syncthreads();
+        for (int t0 = cBegin; t0 < cEnd; t0 += kTT) {
+            const int rows = min(kTT, cEnd - t0);
+            const int nextRows = min(kTT, cEnd - (t0 + kTT));
+            uint4 pre = make_uint4(0, 0, 0, 0);
+            if (tid < nextRows * 2) pre = T[(size_t)(t0 + kTT) * 2 + tid];
+            const uint4* tl = tile[buf];
+            // the next row's 32 bytes are read from LDS while this row is scored (the tile has one row of slack behind it)
+            uint4 lo = tl[0], hi = tl[1];
+            const int rows4 = rows & ~3;
+            for (int j = 0; j < rows4; j += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint4 nlo = tl[2 * (j + u) + 2], nhi = tl[2 * (j + u) + 3];
+                    row_update<R>(q, k1, k2, lo, hi, (uint32_t)(t0 + j + u));
+                    lo = nlo; hi = nhi;
+                }
+            }
+            for (int j = rows4; j < rows; ++j) {
+                const uint4 nlo = tl[2 * j + 2], nhi = tl[2 * j + 3];
+                row_update<R>(q, k1, k2, lo, hi, (uint32_t)(t0 + j));
+                lo = nlo; hi = nhi;
+            }
+            if (tid < nextRows * 2) tile[buf ^ 1][tid] = pre;
+            __syncthreads();
+            buf ^= 1;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int qi = qtile + r * 256 + tid;
+            if (qi < nq) out[qi] = make_uint2(k1[r], k2[r]);
+        }
     }
 }
 
@@ -184,10 +200,18 @@ int knn2_queries_per_lane(int maxQ)
     return maxQ > 2048 ? 4 : maxQ > 512 ? 2 : 1;
 }
 
+// query blocks of a launch: those the sets are expected to fill.  A set handed over by the extractor can hold 32 rows more than it
+// normally does (the quadtree's overshoot slack, 4 per level); the kernel walks on to rows beyond the grid, so this is only balance
+int knn2_query_blocks(int maxQ)
+{
+    const int R = knn2_queries_per_lane(maxQ);
+    return (std::max(maxQ - 32, 1) + 256 * R - 1) / (256 * R);
+}
+
 void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s)
 {
     const int R = knn2_queries_per_lane(maxQ);
-    dim3 grid((maxQ + 256 * R - 1) / (256 * R), a.nChunks, npairs);
+    dim3 grid(knn2_query_blocks(maxQ), a.nChunks, npairs);
     if (R == 4) hipLaunchKernelGGL(k_hamming_knn2<4>, grid, dim3(256), 0, s, a);
     else if (R == 2) hipLaunchKernelGGL(k_hamming_knn2<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_hamming_knn2<1>, grid, dim3(256), 0, s, a);

@@ -227,7 +227,7 @@ def test_failed_allocation_is_reported_and_the_handle_recovers(mods):
     from ssvio_amd import _lib as L
     S, synth, O = mods
     fm = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
-    q, t = synth.descriptor_sets(41, 5000, 5200)                   # > 4096 rows: the copied (not mapped) input path, d_q / d_t grow
+    q, t = synth.descriptor_sets(41, 9000, 9500)                   # > 4096 rows: the copied (not mapped) input path, d_q / d_t grow
     ok, m = fm.MatchByBruteForce(q[:4200], t[:4300])
     want = O.match_bruteforce(q[:4200], t[:4300])
     assert np.array_equal(m.view(np.uint8), want.view(np.uint8))
