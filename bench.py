@@ -441,6 +441,21 @@ def next_rows(ex, fm, d_frames, B, W, H, pairs, dev, iters=20):
         fm.RGBCloud(depth[0], bgr, cam, 10.0)
     t.update(fm.kernel_times())
     fm.set_profiling(False)
+    # Map::MapPointCloudFusion (f4, second half): 8 key-frame clouds of W*H points fused one after the other into a map resident in HBM
+    clouds = [torch.from_numpy(fm.RGBCloud(depth[k], bgr, cam, 10.0).view(np.uint8)).to(dev) for k in range(8)]
+    Ts = [np.eye(4, dtype=np.float32) for _ in range(8)]
+    for k, T in enumerate(Ts):
+        T[:3, 3] = (0.05 * k, 0.01 * k, 0.02 * k)
+    fm.set_profiling(True)
+    wall = []
+    for _ in range(3):
+        fm.MapSet(None)
+        for c, T in zip(clouds, Ts):
+            t0 = time.perf_counter(); fm.MapFuse(c, T, 0.02); wall.append(time.perf_counter() - t0)
+    tv = fm.kernel_times()
+    fm.set_profiling(False)
+    map_points = len(fm.MapFetch()); fm.MapSet(None)
+    vox = {k: round(tv[k][0] * 1e3 / max(tv[k][1], 1), 2) for k in ("k_vox_bounds", "k_vox_keys", "vox_radix_sort", "k_vox_segments", "k_vox_centroid") if k in tv}
     us = lambda k: round(t[k][0] * 1e3 / max(t[k][1], 1), 2) if k in t else None
     return {"workload": "%d frames of %dx%d: MatchByDBoW frame f vs f-1 (vocabulary k=10, L=6, 1111111 nodes, levelsup 4), correspondence "
                         "assembly on its matches, one %dx%d cloud" % (B, W, H, W, H),
@@ -448,7 +463,12 @@ def next_rows(ex, fm, d_frames, B, W, H, pairs, dev, iters=20):
             "launch_covers": {"k_bow_transform": "%d descriptor sets" % B, "k_bow_sort": "%d descriptor sets" % B,
                               "k_match_sorted": "%d frame pairs (2 kernels: match + ordered compaction)" % len(pairs),
                               "k_assemble": "%d frame pairs" % len(pairs), "k_rgb_cloud": "one frame, %d points" % (W * H)},
-            "dbow_matches_per_frame": round(float(nm.mean()), 1)}
+            "dbow_matches_per_frame": round(float(nm.mean()), 1),
+            "map_fusion": {"workload": "Map::MapPointCloudFusion, 8 key-frame clouds of %d points each fused in turn into the device-resident map, "
+                                       "leaf 0.02 (device clouds, ssvio_map_fuse_dev)" % (W * H),
+                           "avg_us_per_launch": vox, "ms_per_key_frame_wall": round(float(np.median(wall)) * 1e3, 3), "map_points_after": map_points,
+                           "note": "k_vox_bounds is the first launch of a call on an idle stream: its hipEvent pair also spans the queue's wake-up "
+                                   "(rocprofv3 --kernel-trace: 11 us, profiles/r2/map_probe_kernel_stats.csv)"}}
 
 
 def trace(msg):
@@ -457,6 +477,9 @@ def trace(msg):
 
 
 def main():
+    if os.environ.get("SSVIO_BENCH_TRACE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(100, exit=False)      # a hang shows where
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -650,7 +673,7 @@ def main():
                                "the wait for CUs held by the other steps' kernels; exclusive_* is the same kernel with one step in flight",
             "rocprof_avg_launch_us": rocprof_avg_us(dom) if prof_ok else None,
             "valu_busy": valu_busy(dom, times[dom][0] * 1e3 / times[dom][1]) if prof_ok else None,
-            "binds": "VALU issue, not HBM: the path is integer byte work with ~60 lane-instructions per pixel (DESIGN.md section 3); the HBM fraction is reported because the contract asks for it",
+            "binds": "VALU issue, not HBM: the path is integer byte work with ~48 lane-instructions per tested pixel (DESIGN.md section 3); the HBM fraction is reported because the contract asks for it",
             "exclusive_avg_launch_us": round(times[dom][0] * 1e3 / times[dom][1], 2),
             "exclusive_frac": round(dom_bytes / (times[dom][0] * 1e-3 / times[dom][1]) / 1e9 / HBM_PEAK_GBS, 5)}
     # the matcher is VALU-bound (xor+popcount), not HBM-bound: report its VALU fraction beside it
@@ -699,13 +722,20 @@ def main():
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(frames, args.features, args.match_mode)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    trace("closing handles")
     for h in exs + fms:
         h.close()
+    trace("handles closed")
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    trace("main done")
 
 
 if __name__ == "__main__":
     main()
+    # every handle is closed and the line is out: leave without the interpreter's and the HIP runtime's teardown, which was seen to
+    # hang once on the GPU box after a complete run (the line had been written, the process never ended)
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)

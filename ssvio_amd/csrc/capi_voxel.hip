@@ -5,10 +5,11 @@
 // PCL is restated (oracle/frame_oracle.c names the version and the one canonical choice: a voxel's points are summed in their
 // order in the concatenated cloud, where PCL's unstable std::sort leaves the order open).  Parity unpinned: PCL is absent.
 //
-// Kernels: k_vox_bounds (transform + append + min/max), k_vox_keys (voxel index per point), rocPRIM radix sort of (index, position)
-// pairs -- LSD radix sort is stable, which IS the canonical order --, k_vox_heads + scan + k_vox_segments (run boundaries),
-// k_vox_centroid (sequential float sums per run in that order; runs longer than 32 points are summed by the whole wave, 64 loads at
-// a time, still added one by one).  HBM-bound gather / scatter work; no host round trip inside a call except the final count.
+// Kernels: k_vox_bounds + k_vox_reduce (transform + append + min/max, no atomics), k_vox_keys (voxel index per point), rocPRIM radix
+// sort of (index, position) pairs -- LSD radix sort is stable, which IS the canonical order --, k_vox_heads + scan + k_vox_segments
+// (run boundaries), k_vox_centroid (sequential float sums per run in that order; a run longer than 32 points is gathered by the whole
+// wave 512 points at a time and added channel by channel, still one by one).  HBM-bound gather / scatter work; no host round trip
+// inside a call except the final count.
 #include "capi_internal.h"
 #include <rocprim/rocprim.hpp>
 #include <cfloat>
@@ -27,17 +28,14 @@ struct VoxState {
 __device__ __forceinline__ uint32_t fkey(float f) { const uint32_t u = __float_as_uint(f); return (u >> 31) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float funkey(uint32_t k) { return __uint_as_float((k >> 31) ? (k & 0x7FFFFFFFu) : ~k); }
 
-__global__ void k_vox_init(VoxState* st)
-{
-    if (threadIdx.x < 3) { st->mn[threadIdx.x] = 0xFFFFFFFFu; st->mx[threadIdx.x] = 0u; }
-    if (threadIdx.x == 3) { st->nonFinite = 0; st->overflow = 0; st->total = 0; st->pad = 0; }
-}
-
 struct Mat34 { float m[3][4]; };
 
-// P[nf + i] = transform(cloud[i]) (src/Map.cpp:181, pcl::transformPointCloud on a dense cloud); min / max over all of P
-__global__ __launch_bounds__(256) void k_vox_bounds(Pt* __restrict__ P, int nf, const Pt* __restrict__ cloud, int nc, Mat34 M, VoxState* st)
+// P[nf + i] = transform(cloud[i]) (src/Map.cpp:181, pcl::transformPointCloud on a dense cloud); min / max over all of P as one
+// record of 7 words per workgroup (min xyz, max xyz, non-finite flag).  No atomics: the clouds arrive in column order, so a bound
+// would improve wave after wave and every wave would queue on the same six addresses.
+__global__ __launch_bounds__(256) void k_vox_bounds(Pt* __restrict__ P, int nf, const Pt* __restrict__ cloud, int nc, Mat34 M, uint32_t* __restrict__ part)
 {
+    __shared__ uint32_t red[4][7];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int n = nf + nc;
     float x = 0, y = 0, z = 0; bool live = i < n;
@@ -58,11 +56,45 @@ __global__ __launch_bounds__(256) void k_vox_bounds(Pt* __restrict__ P, int nf, 
     for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
         for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], (uint32_t)__shfl_xor((int)lo[k], o)); hi[k] = max(hi[k], (uint32_t)__shfl_xor((int)hi[k], o)); }
+    const int w = threadIdx.x >> 6;
+    const unsigned long long anyBad = __ballot(bad);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { atomicMin(&st->mn[k], lo[k]); atomicMax(&st->mx[k], hi[k]); }
+        for (int k = 0; k < 3; ++k) { red[w][k] = lo[k]; red[w][3 + k] = hi[k]; }
+        red[w][6] = anyBad ? 1u : 0u;
     }
-    if (__ballot(bad) && (threadIdx.x & 63) == 0) st->nonFinite = 1;
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int k = threadIdx.x;
+        uint32_t v = red[0][k];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) v = k < 3 ? min(v, red[q][k]) : max(v, red[q][k]);
+        part[(size_t)blockIdx.x * 7 + k] = v;
+    }
+}
+
+// the workgroups' records -> the state block (one workgroup; also resets the flags of the call)
+__global__ __launch_bounds__(256) void k_vox_reduce(const uint32_t* __restrict__ part, int nb, VoxState* st)
+{
+    __shared__ uint32_t red[4][7];
+    uint32_t v[7] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u};
+    for (int b = threadIdx.x; b < nb; b += 256)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { const uint32_t t = part[(size_t)b * 7 + k]; v[k] = k < 3 ? min(v[k], t) : max(v[k], t); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { const uint32_t t = (uint32_t)__shfl_xor((int)v[k], o); v[k] = k < 3 ? min(v[k], t) : max(v[k], t); }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int k = threadIdx.x;
+        uint32_t r = red[0][k];
+        for (int q = 1; q < 4; ++q) r = k < 3 ? min(r, red[q][k]) : max(r, red[q][k]);
+        if (k < 3) st->mn[k] = r; else if (k < 6) st->mx[k - 3] = r; else { st->nonFinite = (int)r; st->overflow = 0; st->total = 0; st->pad = 0; }
+    }
 }
 
 // pcl::VoxelGrid::applyFilter, first pass: the voxel index of every point
@@ -119,14 +151,15 @@ __device__ __forceinline__ Pt acc_get(const Acc& s, int n)
 }
 
 constexpr int kVoxShort = 32;
-// fourth pass: one output point per run, its points added one by one in sorted (= input) order
-__global__ __launch_bounds__(256) void k_vox_centroid(const Pt* __restrict__ P, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ segStart,
-                                                      const VoxState* __restrict__ st, Pt* __restrict__ out)
+constexpr int kVoxDeep = 8;                      // points per lane and step of a long run: 512 points in flight per wave
+// fourth pass: one output point per run, its points added one by one in sorted (= input) order.  One wave per workgroup.
+__global__ __launch_bounds__(64) void k_vox_centroid(const Pt* __restrict__ P, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ segStart,
+                                                     const VoxState* __restrict__ st, Pt* __restrict__ out)
 {
     const int total = st->total;
-    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.x * 64 + threadIdx.x;
     if (__builtin_amdgcn_readfirstlane(v) >= total) return;            // the wave's first voxel: wave-uniform exit
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
     int s = 0, e = 0;
     if (v < total) { s = (int)segStart[v]; e = (int)segStart[v + 1]; }
     const bool isLong = e - s > kVoxShort;
@@ -135,21 +168,53 @@ __global__ __launch_bounds__(256) void k_vox_centroid(const Pt* __restrict__ P, 
         for (int j = s; j < e; ++j) acc_add(a, P[vals[j]]);
         out[v] = acc_get(a, e - s);
     }
-    // long runs (e.g. every zero-depth pixel of a frame lands on one point): the wave loads 64 points at a time and every lane
-    // adds them in order -- the same sequence of float additions, with coalesced loads
+    // long runs (e.g. every zero-depth pixel of a frame lands on one point): the wave gathers 512 points per step (coalesced index
+    // loads, 8 independent point loads per lane), lays their seven summands out channel-major in LDS, and lane c < 7 adds channel
+    // c's values in order -- the same sequence of float additions per channel as the short path.  The gathers of step k + 1 and the
+    // index loads of step k + 2 are in flight while step k is summed: the chain of dependent adds is what the run costs.
+    __shared__ float stage[7][64 * kVoxDeep];
     unsigned long long todo = __ballot(isLong);
     while (todo) {
         const int src = __ffsll((long long)todo) - 1; todo &= todo - 1;
         const int ls = __shfl(s, src), le = __shfl(e, src);
-        Acc a{0, 0, 0, 0, 0, 0, 0};
-        for (int j0 = ls; j0 < le; j0 += 64) {
-            const int cnt = min(64, le - j0);
-            Pt p{}; if (lane < cnt) p = P[vals[j0 + lane]];
-            for (int l = 0; l < cnt; ++l) {
-                Pt q; q.x = __shfl(p.x, l); q.y = __shfl(p.y, l); q.z = __shfl(p.z, l); q.rgba = (uint32_t)__shfl((int)p.rgba, l);
-                acc_add(a, q);
+        float acc = 0.0f;                                               // lane c < 7: running sum of channel c (x, y, z, b, g, r, a)
+        constexpr int kStep = 64 * kVoxDeep;
+        // every load is unconditional (positions past the run's end repeat its last point and are never summed): a load under a
+        // lane predicate gets its own wait, and the eight gathers of a step would queue behind each other
+        uint32_t idx[kVoxDeep]; float4 pv[kVoxDeep]; uint32_t pc[kVoxDeep];
+#pragma unroll
+        for (int t = 0; t < kVoxDeep; ++t) idx[t] = vals[min(ls + 64 * t + lane, le - 1)];
+#pragma unroll
+        for (int t = 0; t < kVoxDeep; ++t) { pv[t] = *(const float4*)&P[idx[t]]; pc[t] = P[idx[t]].rgba; }
+#pragma unroll
+        for (int t = 0; t < kVoxDeep; ++t) idx[t] = vals[min(ls + kStep + 64 * t + lane, le - 1)];
+        for (int j0 = ls; j0 < le; j0 += kStep) {
+            const int cnt = min(kStep, le - j0);
+#pragma unroll
+            for (int t = 0; t < kVoxDeep; ++t) {
+                const int q = 64 * t + lane;
+                stage[0][q] = pv[t].x; stage[1][q] = pv[t].y; stage[2][q] = pv[t].z;
+                stage[3][q] = (float)(pc[t] & 255u); stage[4][q] = (float)((pc[t] >> 8) & 255u);
+                stage[5][q] = (float)((pc[t] >> 16) & 255u); stage[6][q] = (float)(pc[t] >> 24);
             }
+#pragma unroll
+            for (int t = 0; t < kVoxDeep; ++t) { pv[t] = *(const float4*)&P[idx[t]]; pc[t] = P[idx[t]].rgba; }
+#pragma unroll
+            for (int t = 0; t < kVoxDeep; ++t) idx[t] = vals[min(j0 + 2 * kStep + 64 * t + lane, le - 1)];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 7) {
+                const float* row = stage[lane];
+                int l = 0;
+                for (; l + 64 <= cnt; l += 64) {
+#pragma unroll
+                    for (int u = 0; u < 64; ++u) acc += row[l + u];
+                }
+                for (; l < cnt; ++l) acc += row[l];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        Acc a;
+        a.x = __shfl(acc, 0); a.y = __shfl(acc, 1); a.z = __shfl(acc, 2); a.b = __shfl(acc, 3); a.g = __shfl(acc, 4); a.r = __shfl(acc, 5); a.a = __shfl(acc, 6);
         if (lane == src) out[v] = acc_get(a, le - ls);
     }
 }
@@ -214,8 +279,8 @@ int voxel_run(ssvio_matcher* m, const Pt* d_cloud, int nc, const float* T, float
     m->h_voxTotal[0] = -1;
     {
         ProfScope p(m->prof, "k_vox_bounds", s);
-        hipLaunchKernelGGL(k_vox_init, dim3(1), dim3(64), 0, s, st);
-        hipLaunchKernelGGL(k_vox_bounds, dim3(nb), dim3(256), 0, s, P, nf, d_cloud, nc, M, st);
+        hipLaunchKernelGGL(k_vox_bounds, dim3(nb), dim3(256), 0, s, P, nf, d_cloud, nc, M, keysOut);      // 7 * nb <= 3 n + 8 words free behind valsIn
+        hipLaunchKernelGGL(k_vox_reduce, dim3(1), dim3(256), 0, s, keysOut, nb, st);
     }
     {
         ProfScope p(m->prof, "k_vox_keys", s);
@@ -233,7 +298,7 @@ int voxel_run(ssvio_matcher* m, const Pt* d_cloud, int nc, const float* T, float
     }
     {
         ProfScope p(m->prof, "k_vox_centroid", s);
-        hipLaunchKernelGGL(k_vox_centroid, dim3(nb), dim3(256), 0, s, P, valsOut, segStart, st, O);
+        hipLaunchKernelGGL(k_vox_centroid, dim3((n + 63) / 64), dim3(64), 0, s, P, valsOut, segStart, st, O);
     }
     SSVIO_HIP(hipGetLastError());
     SSVIO_HIP(hipStreamSynchronize(s));                     // the count of the new map (mapped host memory) sizes the next call
