@@ -400,7 +400,8 @@ static int orb_enqueue(ssvio_orb* h, int batch)
     static const bool noFuse = getenv("SSVIO_NO_RESIZE2") != nullptr;
     for (int l = 1; l < g.nlevels;) {
         ProfScope p(h->prof, "k_resize", s);
-        const bool fuse = !noFuse && (long)g.lv[l].w * g.lv[l].h * batch <= 600000;
+        static const long fuseMaxPx = [] { const char* e = getenv("SSVIO_RESIZE2_MAX_PX"); return e ? atol(e) : 600000l; }();
+        const bool fuse = !noFuse && (long)g.lv[l].w * g.lv[l].h * batch <= fuseMaxPx;
         if (fuse && l + 1 < g.nlevels && h->fuse2[l]) {
             launch_resize2(h->d_pyr, g.frameBytes, h->kl, l, h->d_tabs, h->xTabOff[l], h->yTabOff[l], h->xTabOff[l + 1], h->yTabOff[l + 1], batch, s);
             l += 2;

@@ -223,11 +223,17 @@ __device__ __forceinline__ void merge_chunks(const uint2* __restrict__ partial, 
                                              uint32_t& k1, uint32_t& k2)
 {
     k1 = kKeyInit; k2 = kKeyInit;
-    for (int c = 0; c < nChunks; ++c) {
-        const uint2 p = partial[(size_t)c * maxRows + i];
+    auto take = [&](const uint2 p) {
         k2 = umed3(k1, k2, p.x); k1 = min(k1, p.x);
         k2 = umed3(k1, k2, p.y); k1 = min(k1, p.y);
+    };
+    const uint2* col = partial + i;
+    int c = 0;
+    for (; c + 4 <= nChunks; c += 4) {                   // four loads in flight
+        const uint2 p0 = col[(size_t)c * maxRows], p1 = col[(size_t)(c + 1) * maxRows], p2 = col[(size_t)(c + 2) * maxRows], p3 = col[(size_t)(c + 3) * maxRows];
+        take(p0); take(p1); take(p2); take(p3);
     }
+    for (; c < nChunks; ++c) take(col[(size_t)c * maxRows]);
 }
 
 // fold the nChunks partial lists of every pair into chunk 0 (each thread owns one query row, so in place is safe);
@@ -254,9 +260,13 @@ __global__ __launch_bounds__(256) void k_match_merge(uint2* partial, int nChunks
 //           exists; every train row votes for its nearest query, a query keeps the closest of its voters (lowest train index on
 //           ties).  The votes are scattered with atomicMin on the key (dist << 23 | trainIdx) into the pair's otherwise unused
 //           forward list.
-__global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
+//
+// NT = 256: the lists were folded by k_match_merge (nChunks = 1) or the set is large.  NT = 1024: per-frame sets (a row per thread):
+// the thread merges its row's chunks itself, keeps the two keys in registers for both passes, and no merge launch runs before.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_match_finalize(FinalizeArgs a)
 {
-    __shared__ int wsum[4];
+    __shared__ int wsum[NT / 64];
     __shared__ int sMin;
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int qset = a.pairs ? a.pairs[2 * pair] : 0;
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
 
     if (a.mode == 3) {
         int32_t* raw = a.raw + (size_t)pair * a.maxRows * 3;
-        for (int i = tid; i < nq; i += 256) {
+        for (int i = tid; i < nq; i += NT) {
             uint32_t k1, k2; merge_chunks(P, a.nChunks, a.maxRows, i, k1, k2);
             const int d1 = min((int)(k1 >> 23), 256), d2 = min((int)(k2 >> 23), 256);
             raw[i] = d1 < 256 ? (int)(k1 & 0x7FFFFF) : -1;       // 'dist < bestDist1' with bestDist1 = 256 never fires for 256
@@ -279,21 +289,25 @@ __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
     }
     uint32_t* vote = (uint32_t*)const_cast<uint2*>(P);           // mode 4: [nq] best voter key per query
     if (a.mode == SSVIO_MODE_CROSSCHECK_CV) {
-        for (int i = tid; i < nq; i += 256) __hip_atomic_store(&vote[i], kKeyInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < nq; i += NT) __hip_atomic_store(&vote[i], kKeyInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        for (int t = tid; t < nt; t += 256) {
+        for (int t = tid; t < nt; t += NT) {
             uint32_t r1, r2; merge_chunks(PR, a.nChunksRev, a.maxRows, t, r1, r2);
             const uint32_t q = r1 & 0x7FFFFF;
             if (r1 != kKeyInit && q < (uint32_t)nq) atomicMin(&vote[q], (r1 & ~0x7FFFFFu) | (uint32_t)t);
         }
         __syncthreads();
     }
+    // a row per thread: merged once, kept for both passes
+    const bool held = nq <= NT && a.mode != SSVIO_MODE_CROSSCHECK_CV;
+    uint32_t hk1 = kKeyInit, hk2 = kKeyInit;
+    if (held && tid < nq) merge_chunks(P, a.nChunks, a.maxRows, tid, hk1, hk2);
     int minD = 1 << 20;
     if (a.mode == 0) {
         if (tid == 0) sMin = 1 << 20;
         __syncthreads();
-        for (int i = tid; i < nq; i += 256) {
-            uint32_t k1, k2; merge_chunks(P, a.nChunks, a.maxRows, i, k1, k2);
+        for (int i = tid; i < nq; i += NT) {
+            uint32_t k1 = hk1, k2 = hk2; if (!held) merge_chunks(P, a.nChunks, a.maxRows, i, k1, k2);
             minD = min(minD, (int)(k1 >> 23));
         }
         atomicMin(&sMin, minD);
@@ -302,14 +316,14 @@ __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
     }
     const int lim = max(2 * minD, 30);
     int written = 0;
-    for (int i0 = 0; i0 < nq; i0 += 256) {
+    for (int i0 = 0; i0 < nq; i0 += NT) {
         const int i = i0 + tid;
         bool keep = false; uint32_t k1 = kKeyInit, k2 = kKeyInit;
         if (i < nq && a.mode == SSVIO_MODE_CROSSCHECK_CV) {
             k1 = __hip_atomic_load(&vote[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             keep = k1 != kKeyInit;
         } else if (i < nq) {
-            merge_chunks(P, a.nChunks, a.maxRows, i, k1, k2);
+            if (held) { k1 = hk1; k2 = hk2; } else merge_chunks(P, a.nChunks, a.maxRows, i, k1, k2);
             const int d1 = (int)(k1 >> 23), d2 = min((int)(k2 >> 23), 256);
             if (a.mode == 0) keep = d1 < lim;
             else if (a.mode == 1) keep = d1 <= a.threshold && (float)d1 < a.nnRatio * (float)d2;
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(256) void k_match_finalize(FinalizeArgs a)
             }
         }
         int total;
-        const int off = block_excl_scan(keep ? 1 : 0, wsum, total);
+        const int off = block_excl_scan<NT>(keep ? 1 : 0, wsum, total);
         if (keep) {
             ssvio_dmatch m;
             const int d1 = (int)(k1 >> 23);
@@ -442,7 +456,9 @@ void launch_finalize(const FinalizeArgs& a0, int npairs, int maxQ, int maxT, hip
 {
     FinalizeArgs a = a0;
     a.pairStride = (size_t)a.nChunks * a.maxRows; a.pairStrideRev = (size_t)a.nChunksRev * a.maxRows;
-    if (a.nChunks > 1) {
+    // per-frame sets without a reverse list: one launch, a row per thread (see k_match_finalize)
+    const bool fused = !a.partialRev && a.mode != 3 && maxQ <= 2048 && a.nChunks > 1 && a.nChunks <= 64;
+    if (a.nChunks > 1 && !fused) {
         hipLaunchKernelGGL(k_match_merge, dim3((maxQ + 255) / 256, npairs), dim3(256), 0, s,
                            const_cast<uint2*>(a.partial), a.nChunks, a.maxRows, a.qcounts, a.pairs, 0);
         a.nChunks = 1;
@@ -452,7 +468,8 @@ void launch_finalize(const FinalizeArgs& a0, int npairs, int maxQ, int maxT, hip
                            const_cast<uint2*>(a.partialRev), a.nChunksRev, a.maxRows, a.tcounts, a.pairs, 1);
         a.nChunksRev = 1;
     }
-    hipLaunchKernelGGL(k_match_finalize, dim3(npairs), dim3(256), 0, s, a);
+    if (fused) hipLaunchKernelGGL(k_match_finalize<1024>, dim3(npairs), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(k_match_finalize<256>, dim3(npairs), dim3(256), 0, s, a);
 }
 
 }  // namespace ssvio

@@ -138,7 +138,8 @@ __device__ __forceinline__ uint32_t hamming256(const uint4 alo, const uint4 ahi,
            __popc(ahi.x ^ bhi.x) + __popc(ahi.y ^ bhi.y) + __popc(ahi.z ^ bhi.z) + __popc(ahi.w ^ bhi.w);
 }
 
-// exclusive scan of v over a 256-thread workgroup (wsum: 4 ints of LDS); total = sum over the workgroup
+// exclusive scan of v over an NT-thread workgroup (wsum: NT / 64 ints of LDS); total = sum over the workgroup
+template <int NT = 256>
 __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -150,7 +151,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total)
     __syncthreads();
     int base = 0; total = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { if (i < wid) base += wsum[i]; total += wsum[i]; }
+    for (int i = 0; i < NT / 64; ++i) { if (i < wid) base += wsum[i]; total += wsum[i]; }
     return base + incl - v;
 }
 #endif
