@@ -356,10 +356,11 @@ def extra_configs(dev, frames_vga):
     frames = synth.frame_stream(2000, nfr, H, W)
     pinned = torch.from_numpy(frames).pin_memory()
     p = Pipeline(dev, 1000, S, torch_streams=True)
-    copy_st = torch.cuda.Stream(device=dev)
+    ncopy = int(os.environ.get("SSVIO_BENCH_COPY_STREAMS", "1"))      # a batch goes up in ncopy slices, one copy stream each (measured: 1 -> 122 k, 2 -> 82 k, 4 -> 65 k frames/s: more streams crowd the 4 hardware queues)
+    copy_sts = [torch.cuda.Stream(device=dev) for _ in range(ncopy)]
     nbuf = S + 1
     d_in = [torch.empty((B, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    ready = [torch.cuda.Event() for _ in range(nbuf)]; free = [torch.cuda.Event() for _ in range(nbuf)]
+    ready = [[torch.cuda.Event() for _ in range(ncopy)] for _ in range(nbuf)]; free = [torch.cuda.Event() for _ in range(nbuf)]
     used = [False] * nbuf
     pairs = np.array([[f, (f - 1) % B] for f in range(B)], np.int32)
     state = {"i": 0}
@@ -367,13 +368,15 @@ def extra_configs(dev, frames_vga):
     def sstep():
         i = state["i"]; state["i"] += 1
         b = i % nbuf; chunk = i % (nfr // B)
-        with torch.cuda.stream(copy_st):
-            if used[b]:
-                copy_st.wait_event(free[b])                       # the step that read this buffer has finished
-            d_in[b].copy_(pinned[chunk * B:(chunk + 1) * B], non_blocking=True)
-            ready[b].record(copy_st)
         cs = p.streams[p.n % S]
-        cs.wait_event(ready[b])
+        for c, copy_st in enumerate(copy_sts):
+            f0, f1 = c * B // ncopy, (c + 1) * B // ncopy
+            with torch.cuda.stream(copy_st):
+                if used[b]:
+                    copy_st.wait_event(free[b])                   # the step that read this buffer has finished
+                d_in[b][f0:f1].copy_(pinned[chunk * B + f0:chunk * B + f1], non_blocking=True)
+                ready[b][c].record(copy_st)
+            cs.wait_event(ready[b][c])
         k = p.step(d_in[b], B, W, H, pairs, L.MODE_BRUTEFORCE)
         free[b].record(p.streams[k]); used[b] = True
 
@@ -388,8 +391,8 @@ def extra_configs(dev, frames_vga):
     dt = time.perf_counter() - t0
     kp = float(p.exs[0].last_counts(B).mean())
     p.close()
-    out.append({"config": "configs[1] streamed: %d distinct 640x480 frames in pinned host memory, %d-frame steps, H2D on a copy stream into %d device buffers "
-                          "ahead of %d steps in flight, 1000 features, extract + MatchByBruteForce vs previous frame" % (nfr, B, nbuf, S),
+    out.append({"config": "configs[1] streamed: %d distinct 640x480 frames in pinned host memory, %d-frame steps, H2D on %d copy stream(s) into %d device buffers "
+                          "ahead of %d steps in flight, 1000 features, extract + MatchByBruteForce vs previous frame" % (nfr, B, ncopy, nbuf, S),
                 "value": round(ns * B / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / ns * 1e3, 4), "steps": ns,
                 "residency": "PCIe feed inside the timed region", "h2d_GBps": round(ns * B * W * H / dt / 1e9, 2), "keypoints_per_frame": kp})
 
@@ -611,8 +614,8 @@ def main():
         step()
     sync_all()                           # the library's streams are not torch's: wait for them, then for the device
     torch.cuda.synchronize()
-    if dist: dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0        # this rank's K steps, from the common start to its own last kernel; the job's time is the MAX below
+    if dist: dist.barrier()              # (the closing barrier's own launch + wait is not part of any rank's steps)
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
