@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
 // second source row (always its first row or the one after it) has been reduced, so only the previous
 // and the current row's horizontal sums are live and all control flow is wave-uniform and short.
 constexpr int kResizeSrcRows = 12;
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, size_t pyrFrameBytes,
                                                      unsigned long long srcOff, int srcPitch,
@@ -155,6 +156,13 @@ __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, 
     const uint8_t* S = pyr + (size_t)frame * pyrFrameBytes + srcOff;
     uint8_t* D = pyr + (size_t)frame * pyrFrameBytes + dstOff + 4 * qi - kPadX;
     const int sBeg = ytab[yBeg].x, sEnd = ytab[yEnd - 1].y;                   // wave-uniform
+    // per pixel of the quad: the selector that lays its taps out as (tap0, 0, tap1, 0) and its coefficients (0 .. 2048) as a u16 pair
+    uint32_t selp[4]; ushort2v wa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        selp[i] = ((e.sel0 >> (8 * i)) & 255u) | (((e.sel1 >> (8 * i)) & 255u) << 16) | 0x0c000c00u;
+        wa[i] = ushort2v{(unsigned short)e.a0[i], (unsigned short)e.a1[i]};
+    }
     uint32_t A[kResizeSrcRows], B[kResizeSrcRows], C[kResizeSrcRows];
 #pragma unroll
     for (int j = 0; j < kResizeSrcRows; ++j) {
@@ -167,9 +175,10 @@ __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, 
 #pragma unroll
     for (int j = 0; j < kResizeSrcRows; ++j) {
         const uint32_t w0 = __builtin_amdgcn_alignbyte(B[j], A[j], off), w1 = __builtin_amdgcn_alignbyte(C[j], B[j], off);
-        const uint32_t p0 = __builtin_amdgcn_perm(w1, w0, e.sel0), p1 = __builtin_amdgcn_perm(w1, w0, e.sel1);
+        // pixel i: its two taps as a u16 pair (one v_perm), times its two coefficients (one v_dot2_u32_u16)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Tc[i] = ((int)((p0 >> (8 * i)) & 255u) * e.a0[i] + (int)((p1 >> (8 * i)) & 255u) * e.a1[i]) >> 4;
+        for (int i = 0; i < 4; ++i)
+            Tc[i] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(w1, w0, selp[i])), wa[i], 0u, false) >> 4);
         while (y < yEnd && ty.y - sBeg == j) {           // rows whose second source row is row j
             const bool same = ty.x == ty.y;              // clamped at the bottom edge: both taps on one row
             uint32_t v = 0;
@@ -630,16 +639,20 @@ __device__ __forceinline__ uint32_t blur_col4(const uint32_t (&a)[4], const uint
                                               const uint32_t (&d)[4], const uint32_t (&e)[4], const uint32_t (&f)[4],
                                               const uint32_t (&g)[4])
 {
-    uint32_t out = 0;
+    uint32_t s[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        uint32_t s = 18u * (a[i] + g[i]) + 32768u;
-        s += 34u * (b[i] + f[i]);
-        s += 49u * (c[i] + e[i]);
-        s += 55u * d[i];
-        out |= min(s >> 16, 255u) << (8 * i);
+        s[i] = 18u * (a[i] + g[i]) + 32768u;
+        s[i] += 34u * (b[i] + f[i]);
+        s[i] += 49u * (c[i] + e[i]);
+        s[i] += 55u * d[i];
     }
-    return out;
+    // min(s >> 16, 255) of four pixels into one dword: the high halves as u16 pairs (v_perm), one packed min per pair (the sum of
+    // the kernel is 257, so a saturated neighbourhood reaches 257), the low bytes of the four halves (v_perm)
+    const ushort2v lim = ushort2v{255, 255};
+    const ushort2v p01 = __builtin_elementwise_min(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(s[1], s[0], 0x07060302u)), lim);
+    const ushort2v p23 = __builtin_elementwise_min(__builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(s[3], s[2], 0x07060302u)), lim);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
 }
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, size_t pyrFrameBytes, KLevels kl,
