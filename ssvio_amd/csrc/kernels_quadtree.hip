@@ -395,20 +395,34 @@ extern "C" int ssvio_debug_qt_times(unsigned long long* out) { return (int)hipMe
 #define QT_STAMP(K) do { } while (0)
 #endif
 
-template <int MAXA>
+// LDS of the short form, carved from one dynamic block (the 1024-node form needs 79 KB, above the static limit):
+//   rec[2][MAXA] uint4 | cc[2][4 MAXA + 64] int | skeys[MAXA] u64 | ord2[MAXA] int | lval, lord [LDSKEYS ? 8 MAXA : 0] u32 | split[MAXA] u8
+template <int MAXA, bool LDSKEYS>
+constexpr size_t qt_short_lds_bytes()
+{
+    return (size_t)MAXA * (2 * 16 + 8 + 4 + 1) + 2 * (4 * MAXA + 64) * 4 + (LDSKEYS ? (size_t)2 * kQtRegKeys * MAXA * 4 : 0);
+}
+
+// MAXA = 256, LDSKEYS: quotas up to 253 (every level of 1000 features on VGA), the level's first 2048 keys staged in LDS.
+// MAXA = 1024, !LDSKEYS: quotas up to 1021 (4000 features on 1080p); the keys are staged in the HBM scratch instead (one coalesced
+// round trip before the rounds, one after), so that the workgroup's LDS stays at 79 KB.
+template <int MAXA, bool LDSKEYS>
 __global__ __launch_bounds__(MAXA) void k_quadtree_short(QtArgs a)
 {
     constexpr int THREADS = MAXA, NW = THREADS / 64;
     constexpr int KPT = kQtRegKeys;                // keys per thread kept in registers (and LDS)
-    __shared__ __attribute__((aligned(16))) uint4 rec[2][MAXA];           // node record: {x0 | y0 << 16, x1 | y1 << 16, keys in the node, -}
+    constexpr int POSBITS = MAXA <= 256 ? 8 : 10;  // list position inside the largest-first round's sort key
+    extern __shared__ __attribute__((aligned(16))) unsigned char dynLdsS[];
+    uint4 (*rec)[MAXA] = (uint4 (*)[MAXA])dynLdsS;                        // node record: {x0 | y0 << 16, x1 | y1 << 16, keys in the node, -}
+    int (*cc)[4 * MAXA + 64] = (int (*)[4 * MAXA + 64])(rec + 2);         // quadrant counts, then child list positions, per node; the last
+                                                                          // 64 ints: where the counting atomics of keys that count nowhere land
+    unsigned long long* skeys = (unsigned long long*)(cc + 2);            // the largest-first round's 32-bit sort keys; best key per node at the end
+    int* ord2 = (int*)(skeys + MAXA);
+    uint32_t* lval = (uint32_t*)(ord2 + MAXA);                            // the level's first keys: value, order key (LDSKEYS only)
+    uint32_t* lord = lval + (LDSKEYS ? KPT * THREADS : 0);
+    unsigned char* split = (unsigned char*)(lord + (LDSKEYS ? KPT * THREADS : 0));
     __shared__ int rootCnt0[kMaxRoots];
     __shared__ __attribute__((aligned(16))) uint4 rootTab[kMaxRoots];     // per root: {rectangle, keys, list position}
-    __shared__ __attribute__((aligned(16))) int cc[2][4 * MAXA + 64];     // quadrant counts, then child list positions, per node; the last
-                                                                          // 64 ints: where the counting atomics of keys that count nowhere land
-    __shared__ __attribute__((aligned(16))) unsigned long long skeys[MAXA];   // the largest-first round's 32-bit sort keys; best key per node at the end
-    __shared__ int ord2[MAXA];
-    __shared__ unsigned char split[MAXA];
-    __shared__ uint32_t lval[KPT * THREADS], lord[KPT * THREADS];          // the level's first keys: value, order key
     __shared__ int slots[4][NW];
     __shared__ int shN, shExp[2], shNc;
 
@@ -457,7 +471,7 @@ __global__ __launch_bounds__(MAXA) void k_quadtree_short(QtArgs a)
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 if (useMask & (1u << j)) {
-                    if (pos < KPT * THREADS) { lval[pos] = e[j].y; lord[pos] = e[j].x & 0x3FFFFFFFu; }
+                    if (LDSKEYS && pos < KPT * THREADS) { lval[pos] = e[j].y; lord[pos] = e[j].x & 0x3FFFFFFFu; }
                     else { kval[pos] = e[j].y; kord[pos] = e[j].x & 0x3FFFFFFFu; }
                     ++pos;
                 }
@@ -470,7 +484,7 @@ __global__ __launch_bounds__(MAXA) void k_quadtree_short(QtArgs a)
     if (n == 0) { if (tid == 0) *selCount = 0; return; }
     uint32_t rv[KPT]; int rn[KPT]; uint2 rr[KPT];            // per key: value, list position of its node, that node's rectangle
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) { const int k = tid + j * THREADS; rv[j] = k < n ? lval[k] : 0u; rn[j] = 0; }
+    for (int j = 0; j < KPT; ++j) { const int k = tid + j * THREADS; rv[j] = k < n ? (LDSKEYS ? lval[k] : kval[k]) : 0u; rn[j] = 0; }
     const int nReg = min(n, KPT * THREADS);                  // keys [nReg, n) use kval / kord / knode in HBM
 
     // ---- 1. roots (:574-619)
@@ -588,7 +602,7 @@ __global__ __launch_bounds__(MAXA) void k_quadtree_short(QtArgs a)
             // largest first, ties: latest created (= smaller list position) first (= ascending sort() walked from the back, :716-717).
             // 32-bit keys: a node holds fewer than 2^24 keys (a level has at most 4128^2 / 4 candidates).
             uint32_t* sk = (uint32_t*)skeys;
-            if (e) sk[eBase] = ((uint32_t)myC << 8) | (uint32_t)(MAXA - 1 - i);
+            if (e) sk[eBase] = ((uint32_t)myC << POSBITS) | (uint32_t)(MAXA - 1 - i);
             if (tid >= nE && tid < ((nE + 3) & ~3)) sk[tid] = 0;     // pad the last group of four
             split[i] = 0;
             __syncthreads();
@@ -599,7 +613,7 @@ __global__ __launch_bounds__(MAXA) void k_quadtree_short(QtArgs a)
                     const uint4 k4 = *(const uint4*)&sk[u];
                     rank += (k4.x > me) + (k4.y > me) + (k4.z > me) + (k4.w > me);
                 }
-                ord2[rank] = MAXA - 1 - (int)(me & 0xFF);
+                ord2[rank] = MAXA - 1 - (int)(me & ((1u << POSBITS) - 1u));
             }
             __syncthreads();
             int qd = 0;
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(MAXA) void k_quadtree_short(QtArgs a)
         atomicMax(&best[nd], key);
     };
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) { const int k = tid + j * THREADS; if (k < n) offer(rn[j], rv[j], lord[k]); }
+    for (int j = 0; j < KPT; ++j) { const int k = tid + j * THREADS; if (k < n) offer(rn[j], rv[j], LDSKEYS ? lord[k] : kord[k]); }
     for (int k = nReg + tid; k < n; k += THREADS) offer(knode[k], kval[k], kord[k]);
     __syncthreads();
     if (tid < Lsize) {
@@ -735,6 +749,7 @@ void quadtree_prepare()
         (void)hipFuncSetAttribute((const void*)k_quadtree<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(256));
         (void)hipFuncSetAttribute((const void*)k_quadtree<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(1024));
         (void)hipFuncSetAttribute((const void*)k_quadtree<2048, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quadtree_lds_bytes(2048));
+        (void)hipFuncSetAttribute((const void*)k_quadtree_short<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(qt_short_lds_bytes<1024, false>()));
         attrSet = true;
     }
 }
@@ -745,7 +760,13 @@ int launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipSt
     // the smallest node capacity that holds quota + 3: 19 KB of LDS at 256 nodes (73 KB at 1024), so that the workgroups of
     // other kernels (k_fast, k_describe of the step in flight beside this one) still fit on the CU
     static const bool longForm = getenv("SSVIO_QUADTREE_LONG") != nullptr;      // measuring knob: the round structure with ~15 barriers
-    if (!longForm && maxAlive <= 256) hipLaunchKernelGGL((k_quadtree_short<256>), dim3(nlevels * batch), dim3(256), 0, s, a);
+    unsigned maxRawCap = 0;
+    for (int l = 0; l < nlevels; ++l) maxRawCap = std::max(maxRawCap, a.kl.lv[l].rawCap);
+    // (the largest-first round's sort key holds a node's key count above 10 bits of list position: levels of up to 2^22 candidates)
+    constexpr size_t lds256 = qt_short_lds_bytes<256, true>(), lds1024 = qt_short_lds_bytes<1024, false>();
+    if (!longForm && maxAlive <= 256) hipLaunchKernelGGL((k_quadtree_short<256, true>), dim3(nlevels * batch), dim3(256), lds256, s, a);
+    else if (!longForm && maxAlive <= 1024 && maxRawCap < (1u << 22))
+        hipLaunchKernelGGL((k_quadtree_short<1024, false>), dim3(nlevels * batch), dim3(1024), lds1024, s, a);
     else if (maxAlive <= 256) hipLaunchKernelGGL((k_quadtree<256, false>), dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(256), s, a);
     else if (maxAlive <= 1024) hipLaunchKernelGGL((k_quadtree<1024, false>), dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(1024), s, a);
     else if (maxAlive <= 2048) hipLaunchKernelGGL((k_quadtree<2048, false>), dim3(nlevels * batch), dim3(kQtThreads), quadtree_lds_bytes(2048), s, a);

@@ -3,11 +3,12 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 import ssvio_amd
 from ssvio_amd import synth, _lib as L
-frames = synth.frame_stream(1000, 2, 480, 640)
+W, H, NF = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (640, 480, 1000)))     # needs a -DSSVIO_QT_TIMING build of kernels_quadtree.hip
+frames = synth.frame_stream(1000, 2, H, W)
 d = torch.from_numpy(frames).cuda()
-ex = ssvio_amd.ORBextractor(1000, 1.2, 8, 20, 7)
+ex = ssvio_amd.ORBextractor(NF, 1.2, 8, 20, 7)
 for _ in range(5):
-    ex.extract_batch_dev(d, 1, 640, 480)
+    ex.extract_batch_dev(d, 1, W, H)
 out = (C.c_ulonglong * 64)()
 lib = L.lib()
 print("rc", lib.ssvio_debug_qt_times(out))
