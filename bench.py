@@ -740,4 +740,5 @@ if __name__ == "__main__":
     # every handle is closed and the line is out: leave without the interpreter's and the HIP runtime's teardown, which was seen to
     # hang once on the GPU box after a complete run (the line had been written, the process never ended)
     sys.stdout.flush(); sys.stderr.flush()
-    os._exit(0)
+    if not (os.environ.get("SSVIO_BENCH_SOFT_EXIT") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)):   # a profiler writes its files at exit
+        os._exit(0)
