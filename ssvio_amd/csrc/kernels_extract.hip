@@ -348,25 +348,21 @@ constexpr int kFtPitch = 72;                 // LDS row bytes: x0-4 .. x0+67
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 
-// cv::FAST corner score from the 16 ring differences d[k] = v - ring[k]:
-//   dark arcs:   max over the 16 circular arcs of 9 of min(d)
-//   bright arcs: max over arcs of min(-d) = -(min over arcs of max(d))
-// score = max(dark, bright) - 1.  Windows of 9 = three windows of 3 (v_min3 / v_max3): 96 instructions.
-__device__ __forceinline__ int arc9_score(const int (&d)[16])
+// cv::FAST's corner score is max(dark, bright) - 1 with dark = max over the 16 circular arcs of 9 of min(v - ring) and bright the
+// same on ring - v; it does not depend on the threshold.  Windows of 9 = three windows of 3 (v_min3).
+// One polarity only: max over the 16 arcs of min(d) - 1 for d[k] = v - ring[k] (dark) or ring[k] - v (bright).  A pixel has a
+// 9-arc in at most one polarity (two would need 18 ring pixels), and where it has one, the other polarity's value is negative
+// (every other 9-arc contains at least two pixels of that arc), so for a corner this IS cv::FAST's score.  48 instructions.
+__device__ __forceinline__ int arc9_score_one(const int (&d)[16])
 {
-    int mn3[16], mx3[16];
+    int mn3[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-        mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-    }
-    int a = -512, b = 512;
+    for (int k = 0; k < 16; ++k) mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    int a = -512;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        a = max(a, min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
-        b = min(b, max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]));
-    }
-    return max(a, -b) - 1;
+    for (int k = 0; k < 16; k += 2)
+        a = max(max(a, min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15])), min(min(mn3[k + 1], mn3[(k + 4) & 15]), mn3[(k + 7) & 15]));
+    return a - 1;
 }
 
 template <bool TALL>
@@ -435,13 +431,18 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     const uint8_t* tb = (const uint8_t*)tile;
     // tested columns of this tile's score domain x0-1 .. x0+64, as positions in a score row (x = x0 - 4 + position)
     const int cLo = max(x0 - 1, kEdge) - (x0 - 4), cHi = min(x0 + kFtW, w - kEdge - 1) - (x0 - 4);
-    // phase 1, packed: a 9-arc always contains two ADJACENT compass pixels (ring 0,4,8,12); "some adjacent
-    // compass pair in one class" == (down|up) & (left|right) per class.  Two pixels per packed-i16 register.
+    // phase 1, bit-parallel: a 9-arc always contains two ADJACENT compass pixels (ring 0,4,8,12); "some adjacent compass pair in
+    // one class" == (down|up) & (left|right) per class.  It is only a NECESSARY test (phase 2 scores exactly), so it runs on the
+    // pixels' upper 7 bits, four pixels per instruction, with add / sub / and / or only (the fast issue class):
+    //   v - X > T  =>  (v >> 1) - (X >> 1) >= ceil(T / 2) =: t,   X - v > T  =>  (X >> 1) - (v >> 1) >= t
+    // and for 7-bit fields a, b in the bytes of a dword, bit 7 of ((a | 0x80) - b) says a >= b with no borrow between the bytes.
+    // 3 % more pixels pass than with the full 8 bits (measured on the bench's frames); none fewer.
     // Domain: score rows y0-1 .. y0+th (r = 0..th+1), quad columns x0-4 .. x0+67 (pixels outside cLo .. cHi dropped).
-    unsigned flags = 0;                                     // bit (8i+k): pixel i of this thread's quad of pass k survives (kScanPasses <= 5)
-    const short2v T2 = short2v{(short)tLow, (short)tLow};
+    unsigned flagsD = 0, flagsB = 0;                        // bit (8i+k): pixel i of this thread's quad of pass k survives the darker / brighter test (kScanPasses <= 5)
+    constexpr uint32_t H = 0x80808080u, M7 = 0x7f7f7f7fu;
+    const uint32_t tq = (uint32_t)min((tLow + 1) >> 1, 128) * 0x01010101u;
     const int qc = c0;
-    // One sign byte per pixel.  A thread's four columns are the same in every pass: their mask is built once.
+    // One flag byte (0x80) per pixel.  A thread's four columns are the same in every pass: their mask is built once.
     uint32_t colMask = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (lane252 && 4 * qc + i >= cLo && 4 * qc + i <= cHi) colMask |= 0x80u << (8 * i);
@@ -456,25 +457,20 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
         const uint32_t U = tile[rowC - 3 * (kFtPitch / 4) + qc], D = tile[rowC + 3 * (kFtPitch / 4) + qc];
         const uint32_t lw = __builtin_amdgcn_alignbyte(C, Lf, 1);     // bytes x-3 .. x
         const uint32_t rw = __builtin_amdgcn_alignbyte(Rt, C, 3);     // bytes x+3 .. x+6
-        uint32_t sgn[2];
-#pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-            const uint32_t sel = hlf ? 0x0c030c02u : 0x0c010c00u;      // bytes (0,1) or (2,3) -> two u16
-            auto pk = [&](uint32_t x) { return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, x, sel)); };
-            const short2v v = pk(C), pu = pk(U), pd = pk(D), pl = pk(lw), pr = pk(rw);
-            // darker than v-T on one vertical AND one horizontal compass pixel:  v - max(min(U,D), min(L,R)) > T
-            const short2v A = __builtin_elementwise_max(__builtin_elementwise_min(pu, pd), __builtin_elementwise_min(pl, pr));
-            // brighter than v+T:  min(max(U,D), max(L,R)) - v > T
-            const short2v B = __builtin_elementwise_min(__builtin_elementwise_max(pu, pd), __builtin_elementwise_max(pl, pr));
-            sgn[hlf] = __builtin_bit_cast(uint32_t, (short2v)(T2 - __builtin_elementwise_max(v - A, B - v)));      // negative <=> passes
-        }
-        // the four sign bytes (pixels 0..3) in one dword
-        const uint32_t f4 = __builtin_amdgcn_perm(sgn[1], sgn[0], 0x07050301u) & (rowOk ? colMask : 0u);
-        flags |= f4 >> (7 - k);
+        const uint32_t c = (C >> 1) & M7, u = (U >> 1) & M7, d = (D >> 1) & M7, l = (lw >> 1) & M7, rr = (rw >> 1) & M7;
+        // darker: c - t >= X on one vertical AND one horizontal compass pixel (bit 7 of P: c >= t at all)
+        const uint32_t P = (c | H) - tq, Ad = P | H;
+        const uint32_t dk = (((Ad - u) | (Ad - d)) & ((Ad - l) | (Ad - rr))) & P;
+        // brighter: X >= c + t (bit 7 of Q: c + t is beyond any 7-bit value)
+        const uint32_t Q = c + tq, Bq = Q & M7;
+        const uint32_t br = ((((u | H) - Bq) | ((d | H) - Bq)) & (((l | H) - Bq) | ((rr | H) - Bq))) & (Q ^ H);
+        const uint32_t okMask = rowOk ? colMask : 0u;
+        flagsD |= (dk & okMask) >> (7 - k);
+        flagsB |= (br & okMask) >> (7 - k);
     }
     {   // one queue reservation per wave
         const int lane = tid & 63;
-        const int cnt = __popc(flags);
+        const int cnt = __popc(flagsD) + __popc(flagsB);
         // inclusive scan over the wave in six DPP adds: shifts by 1, 2, 4, 8 inside the rows of 16, then lane 15 / lane 31 carried on
         int incl = cnt;
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
@@ -489,10 +485,17 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
             if (lane == 63) base = atomicAdd(&qn, tot);
             base = __builtin_amdgcn_readlane(base, 63) + incl - cnt;
             const int e0 = r0 * kFtPitch + 4 * qc;              // byte index of this thread's first quad in the score tile
-            unsigned f = flags;
+            // an entry = position | polarity << 15 (a pixel that passes both tests is queued twice; at most one of the two is a corner)
+            unsigned f = flagsD;
             while (f) {
                 const int bit = __ffs(f) - 1; f &= f - 1;
                 if (base < kFtQueueCap) queue[base] = (uint16_t)(e0 + (bit & 7) * (14 * kFtPitch) + (bit >> 3));
+                ++base;
+            }
+            f = flagsB;
+            while (f) {
+                const int bit = __ffs(f) - 1; f &= f - 1;
+                if (base < kFtQueueCap) queue[base] = (uint16_t)((e0 + (bit & 7) * (14 * kFtPitch) + (bit >> 3)) | 0x8000);
                 ++base;
             }
         }
@@ -500,17 +503,17 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     __syncthreads();
     const int nq = qn;
     // phase 2: exact score of the queued pixels; the corners among them go on to a second, dense queue
-    auto score = [&](int p) -> bool {
+    auto score = [&](int p, int bright) -> bool {
         const uint8_t* c = tb + p + 3 * kFtPitch;               // score row r <-> input row r + 3, same columns
-        const int v = c[0];
+        const int nsg = bright ? 1 : -1, sv = bright ? -(int)c[0] : (int)c[0];
         int d[16];
-#define RING(K, OFF) d[K] = v - c[OFF];
+#define RING(K, OFF) d[K] = __mul24((int)c[OFF], nsg) + sv;
         RING(0, 3 * kFtPitch)      RING(1, 3 * kFtPitch + 1)   RING(2, 2 * kFtPitch + 2)   RING(3, kFtPitch + 3)
         RING(4, 3)                 RING(5, -kFtPitch + 3)      RING(6, -2 * kFtPitch + 2)  RING(7, -3 * kFtPitch + 1)
         RING(8, -3 * kFtPitch)     RING(9, -3 * kFtPitch - 1)  RING(10, -2 * kFtPitch - 2) RING(11, -kFtPitch - 3)
         RING(12, -3)               RING(13, kFtPitch - 3)      RING(14, 2 * kFtPitch - 2)  RING(15, 3 * kFtPitch - 1)
 #undef RING
-        const int s = arc9_score(d);
+        const int s = arc9_score_one(d);
         const bool corner = s >= tLow && s > 0;
         if (corner) ((uint8_t*)sc)[p] = (uint8_t)s;
         return corner;
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
         for (int q0 = 0; q0 < nq; q0 += 256) {                  // waves whose 64 entries lie beyond nq skip the body
             const int q = q0 + tid;
             int p = 0; bool corner = false;
-            if (q < nq) { p = queue[q]; corner = score(p); }
+            if (q < nq) { const int e = queue[q]; p = e & 0x7FFF; corner = score(p, e >> 15); }
             push_corner(corner, p);
         }
     } else {
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
             const int r = (int)(__umul24(e, 14564u) >> 20), cidx = e - r * kFtPitch;
             const int y = y0 - 1 + r;
             bool corner = false;
-            if (e < scRows * kFtPitch && cidx >= cLo && cidx <= cHi && y >= kEdge && y <= h - kEdge - 1) corner = score(e);
+            if (e < scRows * kFtPitch && cidx >= cLo && cidx <= cHi && y >= kEdge && y <= h - kEdge - 1) { corner = score(e, 0); if (!corner) corner = score(e, 1); }
             push_corner(corner, e);
         }
     }
