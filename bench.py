@@ -675,7 +675,9 @@ def main():
                                "the wait for CUs held by the other steps' kernels; exclusive_* is the same kernel with one step in flight",
             "rocprof_avg_launch_us": rocprof_avg_us(dom) if prof_ok else None,
             "valu_busy": valu_busy(dom, times[dom][0] * 1e3 / times[dom][1]) if prof_ok else None,
-            "binds": "VALU issue, not HBM: the path is integer byte work with ~48 lane-instructions per tested pixel (DESIGN.md section 3); the HBM fraction is reported because the contract asks for it",
+            "valu_busy_note": "VALU wave-instructions x 4 cycles over the SIMD cycles of the exclusive launch (2.4 GHz); an upper bound: and / or / add / sub "
+                              "issue in 2.4 cycles on this chip (profiles/r2/ubench_valu_table.txt), so a kernel built from them can read above 1",
+            "binds": "VALU issue, not HBM: the path is integer byte work with ~48 lane-instructions per pyramid pixel (DESIGN.md section 3); the HBM fraction is reported because the contract asks for it",
             "exclusive_avg_launch_us": round(times[dom][0] * 1e3 / times[dom][1], 2),
             "exclusive_frac": round(dom_bytes / (times[dom][0] * 1e-3 / times[dom][1]) / 1e9 / HBM_PEAK_GBS, 5)}
     # the matcher is VALU-bound (xor+popcount), not HBM-bound: report its VALU fraction beside it
