@@ -351,7 +351,7 @@ def extra_configs(dev, frames_vga):
                                     "what": "ORBextractor.Extract + MatchByBruteForce on pageable host arrays (PCIe inclusive, python wrappers)"}})
 
     # ---- configs[1] streamed: 256 distinct frames in pinned host memory, H2D copies on a copy stream, double-buffered against compute
-    B, S, nfr = 64, 3, 256
+    B, S, nfr = 64, int(os.environ.get("SSVIO_BENCH_STREAMED_IN_FLIGHT", "3")), 256
     frames = synth.frame_stream(2000, nfr, H, W)
     pinned = torch.from_numpy(frames).pin_memory()
     p = Pipeline(dev, 1000, S, torch_streams=True)
@@ -399,7 +399,8 @@ def extra_configs(dev, frames_vga):
     W3, H3, B3 = 1920, 1080, 16
     f3 = synth.frame_stream(3000, B3, H3, W3)
     d3 = torch.from_numpy(f3).to(dev)
-    p = Pipeline(dev, 4000, 3)
+    S3 = int(os.environ.get("SSVIO_BENCH_1080P_IN_FLIGHT", "4"))
+    p = Pipeline(dev, 4000, S3)
     pairs3 = np.array([[f, (f - 1) % B3] for f in range(B3)], np.int32)
     for _ in range(6):
         p.step(d3, B3, W3, H3, pairs3, L.MODE_KNN2_RATIO)
@@ -411,9 +412,9 @@ def extra_configs(dev, frames_vga):
     p.sync(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kp3 = float(p.exs[0].last_counts(B3).mean())
-    _, nm3 = p.fms[(p.n - 1) % 3].fetch_batch(counts_only=True)
+    _, nm3 = p.fms[(p.n - 1) % S3].fetch_batch(counts_only=True)
     p.close()
-    out.append({"config": "configs[2]: 1920x1080, 4000 features, 8 levels, extract + kNN2 ratio test vs previous frame, %d-frame steps, 3 in flight" % B3,
+    out.append({"config": "configs[2]: 1920x1080, 4000 features, 8 levels, extract + kNN2 ratio test vs previous frame, %d-frame steps, %d in flight" % (B3, S3),
                 "value": round(n3 * B3 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / n3 * 1e3, 4), "steps": n3,
                 "residency": "device-resident", "keypoints_per_frame": kp3, "matches_per_frame": round(float(nm3.mean()), 1)})
     return out
@@ -498,7 +499,8 @@ def main():
     ap.add_argument("--no-batched-matching", action="store_true", help="skip the configs[3]/[4] matching section")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip configs[0], configs[1] streamed, configs[2] and the sustained run (N = 1 only anyway)")
     ap.add_argument("--sync-steps", action="store_true", help="host waits for every step (latency mode)")
-    ap.add_argument("--streams", type=int, default=3, help="steps in flight: step i runs on handle pair i %% streams, each pair on its own HIP stream")
+    ap.add_argument("--streams", type=int, default=4, help="steps in flight: step i runs on handle pair i %% streams, each pair on its own HIP stream "
+                    "(2 / 3 / 4 / 6 in flight: 260 / 254 / 262 / 263 k frames/s sustained, tools/probe/streams_sweep.sh)")
     ap.add_argument("--no-kernel-events", action="store_true", help="no hipEvent pairs inside the timed region (the roofline entry then uses "
                     "the exclusive pass); lets the library replay its captured hipGraph, which it does not do while kernels are bracketed")
     ap.add_argument("--all-kernel-events", action="store_true", help="hipEvent pairs around every kernel in the timed region (slower)")
