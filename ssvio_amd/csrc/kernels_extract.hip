@@ -47,11 +47,28 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src,
     const uint8_t* s = src + (size_t)frame * frameStride + (size_t)y * stride;
     uint8_t* d = pyr + (size_t)frame * pyrFrameBytes + (size_t)y * pitch0 - kPadX;
     const int nq = (w + 2 * kPadX + 3) >> 2;
+    if (CH == 1 && (aligned4 & 2)) {
+        // 16-byte rows (source pointer, strides and the level's pixel 0 are 16-byte aligned): the interior goes as dwordx4 per lane,
+        // the pad quads and the row's tail as one more pass of single quads
+        const int nv = w >> 4;
+        const uint4* s4 = (const uint4*)s; uint4* d4 = (uint4*)(d + kPadX);
+#pragma unroll 2
+        for (int j = threadIdx.x & 63; j < nv; j += 64) d4[j] = s4[j];
+        const int l = threadIdx.x & 63, q = l == 0 ? 0 : 4 * nv + l;        // quad 0 (left pad), then the quads behind the last 16-byte chunk
+        if (q < nq) {
+            const int x0 = 4 * q - kPadX;
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v |= (uint32_t)s[refl_clamp(x0 + i, w)] << (8 * i);
+            *(uint32_t*)(d + 4 * q) = v;
+        }
+        return;
+    }
 #pragma unroll 4
     for (int q = threadIdx.x & 63; q < nq; q += 64) {
         const int x0 = 4 * q - kPadX;
         uint32_t v = 0;
-        if (CH == 1 && aligned4 && x0 >= 0 && x0 + 3 < w) v = *(const uint32_t*)(s + x0);
+        if (CH == 1 && (aligned4 & 1) && x0 >= 0 && x0 + 3 < w) v = *(const uint32_t*)(s + x0);
         else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -70,7 +87,8 @@ void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frame
                       uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s)
 {
     const int bpf = (h + 3) / 4;
-    const int aligned4 = ((uintptr_t)src % 4 == 0) && (stride % 4 == 0) && (frameStride % 4 == 0);
+    int aligned4 = ((uintptr_t)src % 4 == 0) && (stride % 4 == 0) && (frameStride % 4 == 0);             // bit 0: dword rows, bit 1: 16-byte rows
+    if (((uintptr_t)src % 16 == 0) && (stride % 16 == 0) && (frameStride % 16 == 0) && (pitch0 % 16 == 0) && (pyrFrameBytes % 16 == 0) && ((uintptr_t)pyr % 16 == 0) && w >= 16) aligned4 |= 2;
     hipLaunchKernelGGL(k_level0<1>, dim3(bpf * batch), dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, aligned4, zeroA, nA, zeroB, nB,
                        bpf, batch);
 }
