@@ -429,3 +429,28 @@ def test_fast_queue_overflow_paths(mods, kind, w, h, batch):
     if kind == "uniform":
         assert len(c.level_candidates(0)[0]) > 0.02 * w * h          # the image really is corner-dense
     g.close()
+
+
+@pytest.mark.parametrize("w,stride,off", [(333, 336, 0), (333, 352, 16), (640, 640, 0), (640, 656, 4), (97, 112, 0), (100, 112, 16)])
+def test_level0_row_copy_forms(mods, w, stride, off):
+    """k_level0 copies 16-byte chunks when pointer, strides and pitch allow, dwords when only 4-byte alignment holds, bytes otherwise;
+    rows that do not end on a chunk and the reflect-101 pad quads take the single-quad pass.  Device frames with a row stride and a
+    start offset, two frames per call: level 0 bytes and the end results equal the oracle's."""
+    import torch
+    S, synth, O = mods
+    h = 200 if w > 100 else 97
+    imgs = [synth.texture(900 + w + i, h, w) for i in range(2)]
+    buf = np.full((2, h, stride + 32), 0xAB, np.uint8)               # off + w <= stride + 32
+    for f in range(2):
+        buf[f, :, off:off + w] = imgs[f]
+    d = torch.from_numpy(buf).cuda()
+    nl = 2 if w <= 100 else 4
+    g = S.ORBextractor(300, 1.2, nl, 20, 7); c = O.Extractor(300, 1.2, nl, 20, 7)
+    base = d.data_ptr() + off
+    g.extract_batch_dev(base, 2, w, h, stride=stride + 32, frame_stride=h * (stride + 32))
+    ks, ds, ns = g.fetch_results(2)
+    for f in range(2):
+        rk, rd = c.extract(imgs[f])
+        assert ns[f] == len(rk) and np.array_equal(ks[f, :ns[f]].view(np.uint8), rk.view(np.uint8)) and np.array_equal(ds[f, :ns[f]], rd)
+    assert np.array_equal(g.debug_level_image(0, frame=1), c.level_image(0))
+    g.close()
