@@ -27,6 +27,7 @@
     X(59, "v_fmac_f32 %0, %8, %0")            X(60, "v_max_f32 %0, %0, %8")           X(61, "v_sub_f32 %0, %0, %8") \
     X(62, "v_cvt_f32_i32 %0, %0")            X(63, "v_mad_i32_i24 %0, %0, %8, %0")   X(64, "v_xad_u32 %0, %0, %8, %0") \
     X(65, "v_add_u32 %0, %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD") X(66, "v_max_i16 %0, %0, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2") \
+    X(67, "v_mul_hi_u32 %0, %0, %8")         X(68, "v_bitop3_b32 %0, %0, %8, %0 bitop3:0xc8") X(69, "v_mul_hi_i32_i24 %0, %0, %8") \
     X(43, "v_pk_add_f32 %0, %0, %9")        X(44, "v_pk_mul_f32 %0, %0, %9")
 
 template <int MODE>
