@@ -255,11 +255,9 @@ int voxel_run(ssvio_matcher* m, const Pt* d_cloud, int nc, const float* T, float
     int rc = grow_keep(m->d_mapA, m->mapCapA, (size_t)n * 32, (size_t)nf * 32, s); if (rc) return rc;
     rc = grow(m->d_mapB, m->mapCapB, (size_t)n * 32, s); if (rc) return rc;
     rc = grow(m->d_voxKeys, m->voxKeysCap, (size_t)n * 5 + 8, s); if (rc) return rc;      // keys / vals in, keys / vals out, segStart[n + 1]
-    if (!m->d_voxState) {
-        SSVIO_HIP(hipMalloc(&m->d_voxState, sizeof(VoxState)));
-        SSVIO_HIP(hipHostMalloc((void**)&m->h_voxTotal, 4 * sizeof(int), hipHostMallocMapped));
-        SSVIO_HIP(hipHostGetDevicePointer((void**)&m->d_voxTotal, m->h_voxTotal, 0));
-    }
+    if (!m->d_voxState) SSVIO_HIP(hipMalloc(&m->d_voxState, sizeof(VoxState)));
+    if (!m->h_voxTotal) SSVIO_HIP(hipHostMalloc((void**)&m->h_voxTotal, 4 * sizeof(int), hipHostMallocMapped));      // (each on its own: a failure of one leaves no half-made pair behind)
+    if (!m->d_voxTotal) SSVIO_HIP(hipHostGetDevicePointer((void**)&m->d_voxTotal, m->h_voxTotal, 0));
     uint32_t* keysIn = m->d_voxKeys; uint32_t* valsIn = keysIn + n; uint32_t* keysOut = valsIn + n; uint32_t* valsOut = keysOut + n;
     uint32_t* head = keysIn;            // keysIn / valsIn are dead after the sort: run-head flags and their inclusive scan
     uint32_t* pos = valsIn;
