@@ -351,13 +351,13 @@ def extra_configs(dev, frames_vga):
                                     "what": "ORBextractor.Extract + MatchByBruteForce on pageable host arrays (PCIe inclusive, python wrappers)"}})
 
     # ---- configs[1] streamed: 256 distinct frames in pinned host memory, H2D copies on a copy stream, double-buffered against compute
-    B, S, nfr = 64, int(os.environ.get("SSVIO_BENCH_STREAMED_IN_FLIGHT", "3")), 256
+    B, S, nfr = int(os.environ.get("SSVIO_BENCH_STREAMED_BATCH", "128")), int(os.environ.get("SSVIO_BENCH_STREAMED_IN_FLIGHT", "3")), 256
     frames = synth.frame_stream(2000, nfr, H, W)
     pinned = torch.from_numpy(frames).pin_memory()
     p = Pipeline(dev, 1000, S, torch_streams=True)
     ncopy = int(os.environ.get("SSVIO_BENCH_COPY_STREAMS", "1"))      # a batch goes up in ncopy slices, one copy stream each (measured: 1 -> 122 k, 2 -> 82 k, 4 -> 65 k frames/s: more streams crowd the 4 hardware queues)
     copy_sts = [torch.cuda.Stream(device=dev) for _ in range(ncopy)]
-    nbuf = S + 1
+    nbuf = S + int(os.environ.get("SSVIO_BENCH_STREAMED_SPARE_BUFFERS", "1"))
     d_in = [torch.empty((B, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     ready = [[torch.cuda.Event() for _ in range(ncopy)] for _ in range(nbuf)]; free = [torch.cuda.Event() for _ in range(nbuf)]
     used = [False] * nbuf
