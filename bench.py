@@ -294,6 +294,8 @@ class Pipeline:
         e, m = self.exs[i], self.fms[i]
         self.n += 1
         e.extract_batch_dev(d_frames, B, W, H, wait=wait)
+        if mode is None:                                  # extraction alone
+            return i
         _, d_desc, d_n, cap = e.device_results()
         m.match_batch_dev(d_desc, cap, cap, d_n, pairs, mode)
         if wait:
@@ -417,6 +419,23 @@ def extra_configs(dev, frames_vga):
     out.append({"config": "configs[2]: 1920x1080, 4000 features, 8 levels, extract + kNN2 ratio test vs previous frame, %d-frame steps, %d in flight" % (B3, S3),
                 "value": round(n3 * B3 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / n3 * 1e3, 4), "steps": n3,
                 "residency": "device-resident", "keypoints_per_frame": kp3, "matches_per_frame": round(float(nm3.mean()), 1)})
+
+    # ---- ORB extraction alone (BASELINE's metric names it at both sizes): the same pipelines without the matcher launches
+    def extract_only(d, Bx, Wx, Hx, features, S, n):
+        p = Pipeline(dev, features, S)
+        for _ in range(2 * S):
+            p.step(d, Bx, Wx, Hx, None, None)
+        p.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            p.step(d, Bx, Wx, Hx, None, None)
+        p.sync(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        p.close()
+        return round(n * Bx / dt, 1)
+    dv = torch.from_numpy(synth.frame_stream(1000, 128, H, W)).to(dev)
+    out.append({"config": "ORB extraction alone, device-resident: 640x480 / 1000 features in 128-frame steps, 1920x1080 / 4000 features in %d-frame steps, 4 in flight" % B3,
+                "value": extract_only(dv, 128, W, H, 1000, 4, 120), "unit": "frames/s", "value_1080p": extract_only(d3, B3, W3, H3, 4000, 4, 60)})
     return out
 
 
