@@ -307,7 +307,7 @@ class Pipeline:
             m.sync(); e.sync()
 
     def close(self):
-        for h in self.exs + self.fms:
+        for h in self.fms + self.exs:                     # the matchers run on their extractors' streams: they go first
             h.close()
 
 
@@ -749,7 +749,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     trace("closing handles")
-    for h in exs + fms:
+    for h in fms + exs:                                   # the matchers run on their extractors' streams: they go first
         h.close()
     trace("handles closed")
     if dist:
@@ -760,8 +760,9 @@ def main():
 
 if __name__ == "__main__":
     main()
-    # every handle is closed and the line is out: leave without the interpreter's and the HIP runtime's teardown, which was seen to
-    # hang once on the GPU box after a complete run (the line had been written, the process never ended)
+    # every handle is closed and the line is out: leave without the interpreter's and the HIP runtime's teardown.  (The hang seen
+    # at the end of one run in four turned out to be the bench's own: it destroyed the extractors before the matchers that ran on
+    # their streams; the order is fixed and the library no longer touches a borrowed stream at destroy.  The hard exit stays.)
     sys.stdout.flush(); sys.stderr.flush()
     if not (os.environ.get("SSVIO_BENCH_SOFT_EXIT") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)):   # a profiler writes its files at exit
         os._exit(0)

@@ -151,6 +151,9 @@ int  ssvio_orb_set_stream(ssvio_orb* h, void* hip_stream);
  * The DBoW3 vocabulary it also loads (:8-9) is a separate object here: ssvio_vocab_create below. */
 int  ssvio_matcher_create(int threshold, float nn_ratio, int device, ssvio_matcher** out);
 void ssvio_matcher_destroy(ssvio_matcher* m);
+/* Runs the matcher's work on a caller's stream (NULL: back to its own).  The stream is borrowed: it has to stay alive while
+ * calls are made on the handle; ssvio_matcher_destroy itself does not touch a borrowed stream (it waits for the device),
+ * so the stream's owner -- often the extractor, ssvio_orb_get_stream -- may be destroyed before the matcher. */
 int  ssvio_matcher_set_stream(ssvio_matcher* m, void* hip_stream);
 int  ssvio_matcher_set_profiling(ssvio_matcher* m, int enable);
 int  ssvio_matcher_kernel_times(ssvio_matcher* m, const char** names, double* total_ms, int32_t* launches, int cap, int* count);

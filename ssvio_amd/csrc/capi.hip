@@ -540,9 +540,10 @@ int ssvio_orb_create(const ssvio_orb_params* params, int device, ssvio_orb** out
 void ssvio_orb_destroy(ssvio_orb* h)
 {
     if (!h) return;
-    if (h->gexec) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    // a borrowed stream (ssvio_orb_set_stream) may already be gone: wait for the device instead of touching it
+    if (h->stream == h->own) (void)hipStreamSynchronize(h->stream); else (void)hipDeviceSynchronize();
+    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     h->prof.resolve(); h->prof.destroy();
     orb_free_buffers(h);
     dfree(h->d_tabs);

@@ -252,7 +252,9 @@ void ssvio_matcher_destroy(ssvio_matcher* m)
 {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    (void)hipStreamSynchronize(m->stream);
+    // a borrowed stream (ssvio_matcher_set_stream) may already be gone -- its owner, typically the extractor, is often destroyed
+    // first: wait for the device instead of touching it
+    if (m->stream == m->own) (void)hipStreamSynchronize(m->stream); else (void)hipDeviceSynchronize();
     m->prof.resolve(); m->prof.destroy();
     dfree(m->d_q); dfree(m->d_t); dfree(m->d_counts2); dfree(m->d_partial); dfree(m->d_partialRev);
     dfree(m->d_out); dfree(m->d_raw); dfree(m->d_nout); dfree(m->d_pairs);

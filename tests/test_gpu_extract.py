@@ -454,3 +454,25 @@ def test_level0_row_copy_forms(mods, w, stride, off):
         assert ns[f] == len(rk) and np.array_equal(ks[f, :ns[f]].view(np.uint8), rk.view(np.uint8)) and np.array_equal(ds[f, :ns[f]], rd)
     assert np.array_equal(g.debug_level_image(0, frame=1), c.level_image(0))
     g.close()
+
+
+def test_matcher_outlives_the_extractor_whose_stream_it_borrowed(mods):
+    """ssvio_matcher_set_stream borrows the extractor's stream; destroying the extractor first must leave a matcher that can still
+    be destroyed (its destroy waits for the device instead of touching the stream that is gone).  Run a few times: the failure mode
+    was a hang in one of four process ends of bench.py."""
+    import torch
+    S, synth, O = mods
+    from ssvio_amd import _lib as L
+    frames = torch.from_numpy(synth.frame_stream(5, 4, 240, 320)).cuda()
+    pairs = np.array([[f, (f - 1) % 4] for f in range(4)], np.int32)
+    for _ in range(6):
+        g = S.ORBextractor(500, 1.2, 6, 20, 7); fm = S.FeatureMatching(None, {})
+        fm.set_stream(g.get_stream())
+        g.extract_batch_dev(frames, 4, 320, 240, wait=False)
+        _, d_desc, d_n, cap = g.device_results()
+        fm.match_batch_dev(d_desc, cap, cap, d_n, pairs, L.MODE_BRUTEFORCE)
+        fm.sync()
+        _, n = fm.fetch_batch(counts_only=True)
+        assert (n > 50).all()
+        g.close()                                                # the stream's owner goes first
+        fm.close()
