@@ -169,3 +169,62 @@ def test_random_dbow_configurations_equal_oracle(k, L, levelsup, early, nq, nt, 
     for g_, w_ in zip(fm.ManageMapPoints(kq, dq, cam, T, trk, obs), O.manage_map_points(kq, dq, cam, T, trk, obs)):
         assert np.array_equal(np.ascontiguousarray(g_).view(np.uint8), np.ascontiguousarray(w_).view(np.uint8))
     fm.close(); v.close()
+
+
+def test_one_matcher_handle_across_changing_shapes_and_modes():
+    """A single FeatureMatching handle reused for 40 batches of changing set sizes, pair counts, strides and modes (buffers grow, are
+    reused with other chunkings, hold the previous call's lists): every result equals the oracle's -- nothing read in one call may be
+    a leftover of an earlier one.  Single-pair host calls are mixed in (they share the handle's buffers)."""
+    import torch
+    import ssvio_amd as S
+    from ssvio_amd import synth, _lib as L
+    from oracle import oracle as O
+    rng = np.random.default_rng(2024)
+    fm = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
+    base = synth.descriptor_sets(77, 8, 3000)[1]
+    refs = {0: O.match_bruteforce, 1: lambda a, c: O.match_knn2_ratio(a, c, 50, 0.6), 2: O.match_crosscheck, 4: O.match_crosscheck_cv}
+    for it in range(40):
+        mode = int(rng.choice([0, 1, 2, 4]))
+        nsets = int(rng.integers(2, 7))
+        stride = int(rng.choice([64, 300, 1032, 2100, 3000]))
+        counts = [int(min(stride, c)) for c in rng.choice([0, 1, 5, 63, 64, 65, 200, 513, 1006, 2049, 3000], nsets)]
+        sets = [np.ascontiguousarray(base[rng.permutation(3000)[:c]] ^ np.packbits(rng.random((c, 256)) < 0.04, axis=1, bitorder="little")) for c in counts]
+        buf = np.zeros((nsets, stride, 32), np.uint8)
+        for s, d in enumerate(sets):
+            buf[s, :len(d)] = d
+        pairs = np.array([[rng.integers(0, nsets), rng.integers(0, nsets)] for _ in range(int(rng.integers(1, 9)))], np.int32)
+        fm.match_batch_dev(torch.from_numpy(buf).cuda(), stride, stride, torch.tensor(counts, dtype=torch.int32).cuda(), pairs, mode)
+        fm.sync()
+        out, n = fm.fetch_batch()
+        for p, (a, c) in enumerate(pairs):
+            want = refs[mode](sets[a], sets[c])
+            assert n[p] == len(want) and np.array_equal(out[p, :n[p]].view(np.uint8), want.view(np.uint8)), (it, mode, p, counts[a], counts[c])
+        if it % 5 == 0:                                           # a host single-pair call in between
+            a, c = sets[0], sets[-1]
+            got = fm.MatchByBruteForce(a, c)[1] if len(a) and len(c) else None
+            if got is not None:
+                assert np.array_equal(np.ascontiguousarray(got).view(np.uint8), O.match_bruteforce(a, c).view(np.uint8)), it
+    fm.close()
+
+
+def test_one_extractor_handle_across_changing_sizes_and_batches():
+    """A single ORBextractor handle reused for frames of changing size and batch count (geometry tables rebuilt, buffers regrown and
+    reused): every frame equals the oracle's result."""
+    import ssvio_amd as S
+    from ssvio_amd import synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(99)
+    g = S.ORBextractor(600, 1.2, 6, 20, 7); c = O.Extractor(600, 1.2, 6, 20, 7)
+    sizes = [(320, 240), (640, 480), (203, 151), (640, 480), (800, 600), (256, 256), (320, 240), (1024, 300)]
+    for it, (w, h) in enumerate(sizes):
+        batch = int(rng.integers(1, 5))
+        imgs = np.stack([synth.texture(500 + 10 * it + f, h, w) for f in range(batch)])
+        if (w, h) == (203, 151):                                  # too small for six levels: an error, and the handle stays usable
+            with pytest.raises(S.SsvioError):
+                g.extract_batch(imgs)
+            continue
+        ks, ds, ns = g.extract_batch(imgs)
+        for f in range(batch):
+            rk, rd = c.extract(imgs[f])
+            assert ns[f] == len(rk) and np.array_equal(ks[f, :ns[f]].view(np.uint8), rk.view(np.uint8)) and np.array_equal(ds[f, :ns[f]], rd), (it, w, h, f)
+    g.close()
