@@ -228,3 +228,27 @@ def test_one_extractor_handle_across_changing_sizes_and_batches():
             rk, rd = c.extract(imgs[f])
             assert ns[f] == len(rk) and np.array_equal(ks[f, :ns[f]].view(np.uint8), rk.view(np.uint8)) and np.array_equal(ds[f, :ns[f]], rd), (it, w, h, f)
     g.close()
+
+
+def test_one_dbow_handle_across_changing_shapes():
+    """One vocabulary-bound FeatureMatching handle reused for 14 MatchByDBoW calls of changing set sizes, with brute-force calls and
+    the steps behind the matcher mixed in on the same handle (the sorted views, candidate and staging buffers are reused)."""
+    import ssvio_amd as S
+    from ssvio_amd import synth
+    from oracle import oracle as O
+    par, desc, w = synth.vocabulary_tables(31, 10, 4, stop_p=0.02)
+    v = S.Vocabulary(10, 4, par, desc, w); ov = O.Vocabulary(10, 4, par, desc, w, v.word)
+    fm = S.FeatureMatching(v, {"Threshold": 50, "NNRatio": 0.6})
+    rng = np.random.default_rng(7)
+    u8 = lambda x: np.ascontiguousarray(x).view(np.uint8)
+    for it, (nq, nt) in enumerate([(900, 1000), (30, 2000), (2400, 50), (1, 1), (1000, 1000), (9000, 300), (64, 64), (500, 8300), (1000, 999), (3, 700), (2049, 2047), (100, 100), (1200, 1), (777, 1555)]):
+        t = synth.descriptors_near_leaves(100 + it, nt, par, desc, 0.03)
+        q = t[rng.integers(0, nt, nq)] ^ np.packbits(rng.random((nq, 256)) < 0.03, axis=1, bitorder="little")
+        ok, m = fm.MatchByDBoW(q, t, levelsup=2 + it % 3)
+        assert np.array_equal(u8(m), u8(O.match_dbow(ov, q, t, 50, 0.6, 2 + it % 3))), (it, nq, nt)
+        if it % 3 == 0:
+            assert np.array_equal(u8(fm.MatchByBruteForce(q, t)[1]), u8(O.match_bruteforce(q, t))), it
+        if it % 4 == 1:
+            last = np.zeros(min(nq, 300), S.DM_DTYPE); last["queryIdx"] = rng.integers(0, nt, len(last)); last["trainIdx"] = rng.integers(0, nt, len(last))
+            assert np.array_equal(u8(fm.TrackMapPoints(last, m)), u8(O.track_map_points(last, m))), it
+    fm.close(); v.close()
