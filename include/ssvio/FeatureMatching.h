@@ -46,6 +46,9 @@ public:
     { return run(ssvio_match_knn2_ratio, desp1, desp2, matches); }
     bool MatchByCrossCheck(cv::Mat& desp1, cv::Mat& desp2, std::vector<cv::DMatch>& matches)
     { return run(ssvio_match_crosscheck, desp1, desp2, matches); }
+    // cv::BFMatcher(NORM_HAMMING, true).match(desp1, desp2) the way OpenCV 3.x filters it ("OpenCV-compat")
+    bool MatchByCrossCheckCV(cv::Mat& desp1, cv::Mat& desp2, std::vector<cv::DMatch>& matches)
+    { return run(ssvio_match_crosscheck_cv, desp1, desp2, matches); }
     // DBoW3's typedefs: BowVector = map<WordId, WordValue>, FeatureVector = map<NodeId, vector<unsigned>>
     typedef std::map<unsigned int, double> BowVector;
     typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;

@@ -115,4 +115,30 @@ inline bool ManageMapPoints(FeatureMatching& fm, const std::vector<cv::KeyPoint>
                                    match_num.data(), map_point.data(), &new_point[0].x) == SSVIO_OK;
 }
 
+// ---- Map::MapPointCloudFusion, src/Map.cpp:164-197: the map (_final_cloud) stays on the GPU inside the matcher handle.
+// One MapFuse* call = one iteration of the reference's key-frame loop (transform the frame's cloud by this_trans exactly as
+// written, append, VoxelGrid(voxel_size)); MapFetch = the cloud the reference writes to map.pcd.
+struct PointXYZRGB { float x, y, z, w; unsigned char b, g, r, a; unsigned int pad[3]; };     // pcl::PointXYZRGB, 32 bytes
+static_assert(sizeof(PointXYZRGB) == 32, "pcl::PointXYZRGB layout");
+
+inline bool MapClear(FeatureMatching& fm) { return ssvio_map_set(fm.handle(), nullptr, 0) == SSVIO_OK; }
+// this_trans: the 16 floats of the key frame's Eigen::Matrix4f (data(), column-major)
+inline bool MapFuseCloud(FeatureMatching& fm, const PointXYZRGB* cloud, size_t n, const float* this_trans, float voxel_size)
+{ return ssvio_map_fuse(fm.handle(), cloud, (int)n, this_trans, voxel_size) == SSVIO_OK; }
+// the frame's cloud built on the GPU from its depth (CV_16UC1) and colour (CV_8UC3, BGR) images as XtionCamera::GrabImage does
+// (driver/Xtion_Driver.cpp:219-229), then fused; depth_scale_yaml is the driver's _DepthScale before its division by 65535
+inline bool MapFuseFrame(FeatureMatching& fm, const cv::Mat& depth, const cv::Mat& bgr, const ssvio_camera& cam, float depth_scale_yaml,
+                         const float* this_trans, float voxel_size)
+{
+    return ssvio_map_fuse_frame(fm.handle(), (const uint16_t*)depth.ptr(0), (int)(depth.step / 2), (const uint8_t*)bgr.ptr(0), (int)bgr.step,
+                                depth.cols, depth.rows, &cam, (double)depth_scale_yaml / 65535.0, this_trans, voxel_size) == SSVIO_OK;
+}
+inline bool MapFetch(FeatureMatching& fm, std::vector<PointXYZRGB>& out)
+{
+    int n = 0;
+    if (ssvio_map_fetch(fm.handle(), nullptr, 0, &n) != SSVIO_OK) return false;
+    out.resize((size_t)n);
+    return n == 0 || ssvio_map_fetch(fm.handle(), out.data(), n, &n) == SSVIO_OK;
+}
+
 }  // namespace ssvio

@@ -113,6 +113,19 @@ int main(int argc, char** argv)
             dump((out + ".fin").c_str(), c.final_good_match.data(), c.final_good_match.size() * sizeof(cv::DMatch));
             dump((out + ".trk").c_str(), last.data(), last.size() * sizeof(cv::DMatch));
             dump((out + ".inm").c_str(), inm.data(), inm.size() * 4);
+            // OpenCV-compat cross-check, and Map::MapPointCloudFusion over two key frames (colour = the gray frame in all three channels)
+            std::vector<cv::DMatch> m5;
+            fm->MatchByCrossCheckCV(db, da, m5);
+            if (fm->lastStatus() != SSVIO_OK) { fprintf(stderr, "MatchByCrossCheckCV: %s\n", ssvio_last_error()); return 1; }
+            dump((out + ".m5").c_str(), m5.data(), m5.size() * sizeof(cv::DMatch));
+            std::vector<uint8_t> bgrA((size_t)3 * w * h), bgrB((size_t)3 * w * h);
+            for (size_t i = 0; i < (size_t)w * h; ++i) for (int ch = 0; ch < 3; ++ch) { bgrA[3 * i + ch] = a.data[i]; bgrB[3 * i + ch] = b.data[i]; }
+            cv::Mat cA(h, w, CV_8UC3, bgrA.data(), (size_t)3 * w), cB(h, w, CV_8UC3, bgrB.data(), (size_t)3 * w);
+            const float ident[16] = {1.f, 0.f, 0.f, 0.f,  0.f, 1.f, 0.f, 0.f,  0.f, 0.f, 1.f, 0.f,  0.f, 0.f, 0.f, 1.f};
+            std::vector<ssvio::PointXYZRGB> map;
+            if (!ssvio::MapClear(*fd) || !ssvio::MapFuseFrame(*fd, depA, cA, cam, 10.0f, ident, 0.05f) ||
+                !ssvio::MapFuseFrame(*fd, depB, cB, cam, 10.0f, wt, 0.05f) || !ssvio::MapFetch(*fd, map)) { fprintf(stderr, "map fusion: %s\n", ssvio_last_error()); return 1; }
+            dump((out + ".map").c_str(), map.data(), map.size() * sizeof(ssvio::PointXYZRGB));
             if (argc >= 9) {
                 // the same vocabulary as DBoW3's uncompressed binary stream (what Vocabulary::load tries first): same matches
                 FeatureMatching::Ptr fb = std::make_shared<FeatureMatching>(argv[8], cfg);

@@ -80,3 +80,11 @@ def test_adapters_match_oracle(tmp_path):
     mnum, mpid, npt = O.manage_map_points(kb, depth[1], cam, T, trk, obs)
     assert rd(".mnum") == mnum.tobytes() and rd(".mpid") == mpid.tobytes() and rd(".npt") == npt.tobytes()
     assert (mnum >= 0).any() and (mpid >= 0).any() and (mnum < 0).any()
+    # OpenCV-compat cross-check and two key frames of Map::MapPointCloudFusion through the C++ wrappers
+    assert rd(".m5") == O.match_crosscheck_cv(db, da).tobytes()
+    gray3 = lambda g: np.repeat(g[:, :, None], 3, axis=2)
+    cA = O.rgb_cloud(depth[0], gray3(a), 160.5912, 120.4792, 253.0589, 254.1649, 10.0)
+    cB = O.rgb_cloud(depth[1], gray3(b), 160.5912, 120.4792, 253.0589, 254.1649, 10.0)
+    m1 = O.voxel_fuse(cA[:0], cA, np.eye(4, dtype=np.float32), 0.05)
+    m2 = O.voxel_fuse(m1, cB, T, 0.05)
+    assert rd(".map") == m2.tobytes() and 1000 < len(m2) < len(cA) + len(cB)
