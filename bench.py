@@ -506,7 +506,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="frames per step (64 -> 128 -> 256: 223 k -> 239 k -> 248 k frames/s, tools/probe/batch_sweep.sh)")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step (96 / 128 / 160 / 192 / 256 with four steps in flight: 247 / 251 / 257 / 261 / 264 k frames/s "
+                    "over a 20-step region, tools/probe/k20_grid.sh: the region's fill and drain weigh less the longer it is)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--features", type=int, default=1000)
@@ -683,7 +684,7 @@ def main():
                       "alg_bytes_per_launch": int(ab), "GBps": round(ab / (avg_us * 1e-6) / 1e9, 1) if avg_us > 0 else None}
     if dom_launches == 0:                      # --no-kernel-events: the exclusive pass is the only measurement
         dom_ms, dom_launches = times[dom]
-    prof_ok = profiles_current() and (B, W, H, args.features) == (128, 640, 480, 1000)
+    prof_ok = profiles_current() and (B, W, H, args.features) == (256, 640, 480, 1000)
     dom_avg_s = dom_ms * 1e-3 / dom_launches
     dom_bytes = algorithmic_bytes(dom, B, px, int(counts.sum()), pairs_rows)
     achieved = dom_bytes / dom_avg_s / 1e9
