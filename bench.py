@@ -398,7 +398,7 @@ def extra_configs(dev, frames_vga):
                 "residency": "PCIe feed inside the timed region", "h2d_GBps": round(ns * B * W * H / dt / 1e9, 2), "keypoints_per_frame": kp})
 
     # ---- configs[2]: 1920x1080, 4000 features, extract + kNN2 ratio test (Threshold 50, NNRatio 0.6), 16-frame steps, 3 in flight
-    W3, H3, B3 = 1920, 1080, 16
+    W3, H3, B3 = 1920, 1080, int(os.environ.get("SSVIO_BENCH_1080P_BATCH", "32"))
     f3 = synth.frame_stream(3000, B3, H3, W3)
     d3 = torch.from_numpy(f3).to(dev)
     S3 = int(os.environ.get("SSVIO_BENCH_1080P_IN_FLIGHT", "4"))
