@@ -636,16 +636,14 @@ void launch_fast(const uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, in
 // 32-bit v_mad_u32_u24; one dword store per lane and row.  HBM traffic = the algorithmic
 // 2 bytes per pixel plus a 6-row halo per strip and the two halo lanes.
 // rows carry 4 reflect-101 pad columns on both sides, so every lane that feeds an output loads a plain
-// dword; lanes further out (x > w+3) are clamped onto the last pad dword and feed nobody
-__device__ __forceinline__ uint32_t blur_load4(const uint8_t* __restrict__ row, int x, int w)
-{
-    return *(const uint32_t*)(row + min(x, (w + 3) & ~3));
-}
-
+// dword; lanes further out (x > w+3) are clamped onto the last pad dword and feed nobody.
+// Addresses: the frame's base is wave-uniform (SGPR pair), everything below it is a 32-bit lane offset (a frame's pyramid is
+// far below 4 GB: levels are capped at 4128 px, geometry.cpp), one v_mad_u32_u24 per strip-iteration and an add per row.
 __device__ __forceinline__ void blur_rowsum(uint32_t d1, uint32_t (&r)[4])
 {
-    const uint32_t d0 = __builtin_amdgcn_update_dpp(0u, d1, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1's dword
-    const uint32_t d2 = __builtin_amdgcn_update_dpp(0u, d1, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1's dword
+    // bound_ctrl: the wave's end lanes read 0 (they are halo lanes, their sums feed nobody) and no lane keeps an old value
+    const uint32_t d0 = __builtin_amdgcn_update_dpp(0u, d1, 0x138, 0xf, 0xf, true);    // wave_shr:1 -> lane-1's dword
+    const uint32_t d2 = __builtin_amdgcn_update_dpp(0u, d1, 0x130, 0xf, 0xf, true);    // wave_shl:1 -> lane+1's dword
     const uint32_t WLO = 18u | (34u << 8) | (49u << 16) | (55u << 24);                // x-3 .. x
     const uint32_t WHI = 49u | (34u << 8) | (18u << 16);                              // x+1 .. x+3
 #pragma unroll
@@ -656,6 +654,14 @@ __device__ __forceinline__ void blur_rowsum(uint32_t d1, uint32_t (&r)[4])
     }
 }
 
+template <int K>      // a * K + acc, a < 2^24, K an inline constant
+__device__ __forceinline__ uint32_t mad24k(uint32_t a, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(K), "v"(acc));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t blur_col4(const uint32_t (&a)[4], const uint32_t (&b)[4], const uint32_t (&c)[4],
                                               const uint32_t (&d)[4], const uint32_t (&e)[4], const uint32_t (&f)[4],
                                               const uint32_t (&g)[4])
@@ -663,10 +669,12 @@ __device__ __forceinline__ uint32_t blur_col4(const uint32_t (&a)[4], const uint
     uint32_t s[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        s[i] = 18u * (a[i] + g[i]) + 32768u;
-        s[i] += 34u * (b[i] + f[i]);
-        s[i] += 49u * (c[i] + e[i]);
-        s[i] += 55u * d[i];
+        // row sums are <= 65535, pairs of them < 2^17: a chain of four v_mad_u32_u24 (written out: the compiler turns the
+        // sum of products into four multiplies and two 3-operand adds, two more full-rate-class issue slots per pixel)
+        s[i] = mad24k<18>(a[i] + g[i], 32768u);
+        s[i] = mad24k<34>(b[i] + f[i], s[i]);
+        s[i] = mad24k<49>(c[i] + e[i], s[i]);
+        s[i] = mad24k<55>(d[i], s[i]);
     }
     // min(s >> 16, 255) of four pixels into one dword: the high halves as u16 pairs (v_perm), one packed min per pair (the sum of
     // the kernel is 257, so a saturated neighbourhood reaches 257), the low bytes of the four halves (v_perm)
@@ -693,33 +701,46 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     const int w = L.w, h = L.h, pitch = L.pitch;
     const int iters = live ? L.blurIters : 0;
     const int rows = 7 * iters - 6;
-    const uint8_t* src = pyr + (size_t)frame * pyrFrameBytes + L.offset;
-    uint8_t* dst = blur + (size_t)frame * pyrFrameBytes + L.offset;
+    const uint8_t* fsrc = pyr + (size_t)frame * pyrFrameBytes;      // wave-uniform bases
+    uint8_t* fdst = blur + (size_t)frame * pyrFrameBytes;
     const int x = sx * 120 - 4 + 4 * lane;                 // first of this lane's 4 pixels
     const int y0 = sy * rows;
     const bool writer = lane >= 1 && lane <= 30 && x < w;
+    const uint32_t lbase = (uint32_t)L.offset + (uint32_t)min(x, (w + 3) & ~3);     // offset of this lane's dword in row 0 (x >= -4, offset >= 64)
+    uint32_t sOff = (uint32_t)L.offset + (uint32_t)x + (uint32_t)(y0 - 6) * (uint32_t)pitch;   // store offset of step 0's output row (used from step 6 on)
     uint32_t r0[4], r1[4], r2[4], r3[4], r4[4], r5[4], r6[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) r0[i] = r1[i] = r2[i] = r3[i] = r4[i] = r5[i] = r6[i] = 0;
     // step s consumes input row y0-3+s and (from s >= 6) emits output row y0+s-6.  The 7 loads of
     // the NEXT iteration are issued before the current one is processed (latency hiding).
-#define BLUR_LOAD(S0, S) blur_load4(src + (size_t)min(max(refl101(y0 - 3 + (S0) + (S), h), 0), h - 1) * pitch, x, w)
+    // rows yb .. yb+6: consecutive rows for a strip-iteration inside the image, reflect-101 (and a clamp for the rows past the
+    // last strip's end) at the top and bottom edges
+#define BLUR_LOAD7(DST, YB)                                                                          \
+    {                                                                                                \
+        const int yb = (YB);                                                                         \
+        if (yb >= 0 && yb + 6 < h) {                                                                 \
+            uint32_t o = lbase + __umul24((uint32_t)yb, (uint32_t)pitch);                            \
+            _Pragma("unroll") for (int i = 0; i < 7; ++i) { DST[i] = *(const uint32_t*)(fsrc + o); o += (uint32_t)pitch; } \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 7; ++i)                                            \
+                DST[i] = *(const uint32_t*)(fsrc + (lbase + __umul24((uint32_t)refl_clamp(yb + i, h), (uint32_t)pitch))); \
+        }                                                                                            \
+    }
 #define BLUR_STEP(S, RN, A, B, C, D, E, F, G)                                                        \
     {                                                                                                \
         blur_rowsum(cur[S], RN);                                                                     \
         const int yout = y0 + s0 + (S) - 6;                                                          \
         if (s0 + (S) >= 6 && writer && yout < h)                                                     \
-            *(uint32_t*)(dst + (size_t)yout * pitch + x) = blur_col4(A, B, C, D, E, F, G);           \
+            *(uint32_t*)(fdst + sOff) = blur_col4(A, B, C, D, E, F, G);                              \
+        sOff += (uint32_t)pitch;                                                                     \
     }
     uint32_t cur[7], nxt[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) { cur[i] = iters > 0 ? BLUR_LOAD(0, i) : 0u; nxt[i] = 0; }
+    for (int i = 0; i < 7; ++i) cur[i] = nxt[i] = 0;
+    if (iters > 0) BLUR_LOAD7(cur, y0 - 3)
     for (int it = 0; it < iters; ++it) {
         const int s0 = it * 7;
-        if (it + 1 < iters) {
-#pragma unroll
-            for (int i = 0; i < 7; ++i) nxt[i] = BLUR_LOAD(s0 + 7, i);
-        }
+        if (it + 1 < iters) BLUR_LOAD7(nxt, y0 - 3 + s0 + 7)
         BLUR_STEP(0, r0, r1, r2, r3, r4, r5, r6, r0)
         BLUR_STEP(1, r1, r2, r3, r4, r5, r6, r0, r1)
         BLUR_STEP(2, r2, r3, r4, r5, r6, r0, r1, r2)
@@ -730,7 +751,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 #pragma unroll
         for (int i = 0; i < 7; ++i) cur[i] = nxt[i];
     }
-#undef BLUR_LOAD
+#undef BLUR_LOAD7
 #undef BLUR_STEP
 }
 
