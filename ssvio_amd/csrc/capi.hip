@@ -410,22 +410,32 @@ static int orb_enqueue(ssvio_orb* h, int batch)
             l += 1;
         }
     }
+    // tall FAST tiles halve the per-tile fixed work; short ones give a small batch enough workgroups to fill the chip
+    const bool tall = (long)g.fastTilesPerFrameT * batch >= 2048;
+    // the blur depends on the pyramid only: it runs on the side stream beside k_quadtree (one workgroup per frame-level, which
+    // leaves most of the chip idle) and, for batches that fill the chip, beside k_fast as well (VALU-bound, where the blur moves
+    // bytes: 272.8 k -> 275.2 k frames/s at 256-frame steps; a single frame loses 2.5 % that way - its k_fast is on the critical
+    // path and gives up CUs - so small batches fork after it).  k_describe waits for both.
+    static const bool lateForkEnv = getenv("SSVIO_BLUR_AFTER_FAST") != nullptr;   // the one order of round 2, kept for A/B runs
+    // (with event pairs around every kernel the fork also stays behind k_fast, so that its pair times k_fast alone)
+    const bool lateFork = lateForkEnv || !tall || (h->prof.enabled && !h->prof.only);
+    auto fork_blur = [&]() -> int {
+        SSVIO_HIP(hipEventRecord(h->evFork, s));
+        SSVIO_HIP(hipStreamWaitEvent(h->side, h->evFork, 0));
+        {
+            ProfScope p(h->prof, "k_blur", h->side);
+            launch_blur(h->d_pyr, h->d_blur, g.frameBytes, h->kl, g.blurStripsPerFrame, batch, h->side);
+        }
+        SSVIO_HIP(hipEventRecord(h->evJoin, h->side));
+        return SSVIO_OK;
+    };
+    if (!lateFork) { const int rc = fork_blur(); if (rc) return rc; }
     {
         ProfScope p(h->prof, "k_fast", s);
-        // tall tiles halve the per-tile fixed work; short ones give a small batch enough workgroups to fill the chip
-        const bool tall = (long)g.fastTilesPerFrameT * batch >= 2048;
         launch_fast(h->d_pyr, g.frameBytes, h->kl, tall ? g.fastTilesPerFrameT : g.fastTilesPerFrame, tall, g.cellsPerFrame, g.slotsPerFrame, h->tab.iniTh, h->tab.minTh,
                     h->d_raw, h->d_rawCount, h->d_cellIni, batch, s);
     }
-    // the blur depends on the pyramid only: it runs on the side stream beside k_quadtree (one workgroup per frame-level,
-    // which leaves most of the chip idle), and k_describe waits for both
-    SSVIO_HIP(hipEventRecord(h->evFork, s));
-    SSVIO_HIP(hipStreamWaitEvent(h->side, h->evFork, 0));
-    {
-        ProfScope p(h->prof, "k_blur", h->side);
-        launch_blur(h->d_pyr, h->d_blur, g.frameBytes, h->kl, g.blurStripsPerFrame, batch, h->side);
-    }
-    SSVIO_HIP(hipEventRecord(h->evJoin, h->side));
+    if (lateFork) { const int rc = fork_blur(); if (rc) return rc; }
     if (!h->hostQuadtree) {
         QtArgs a{};
         a.kl = h->kl; a.raw = h->d_raw; a.rawCount = h->d_rawCount; a.cellIni = h->d_cellIni;
