@@ -859,11 +859,18 @@ constexpr IcRowMasks make_ic_masks()
 }
 __constant__ IcRowMasks c_icmask = make_ic_masks();
 
-__device__ __forceinline__ int half_sum(int v)          // sum over the 32 lanes of the lane's half-wave
+// sum over the 32 lanes of the lane's half-wave, in the VALU: an inclusive DPP scan inside the rows of 16, lane 15 carried into
+// the next row (rows 1 and 3), which leaves the halves' sums in lanes 31 and 63 (five adds instead of five LDS-crossbar shuffles
+// on the one serial chain of the wave)
+__device__ __forceinline__ int half_sum(int v, int half)
 {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+    return half ? hi : lo;
 }
 
 // orientation + descriptor + final KeyPoint: TWO keypoints per wave (one per 32-lane half), so that the per-keypoint
@@ -891,9 +898,11 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
     {
         const int l = sl & 15;
         int incl = l < kl.nlevels ? selCount[frame * kMaxLevels + l] : 0;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(incl, o, 16); if (l >= o) incl += t; }
-        total = __shfl(incl, 15, 16);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);      // row_shr 1, 2, 4, 8: inclusive scan inside each row of 16
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+        total = __builtin_amdgcn_readlane(incl, 15);
         const unsigned long long vote = __ballot(sl < kl.nlevels && incl <= k);
         level = __popc(half ? (uint32_t)(vote >> 32) : (uint32_t)vote);
         before = __shfl(incl, max(level - 1, 0), 16);                 // lanes 0..15 of the same half
@@ -923,19 +932,23 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
     const unsigned sh = ip & 3u; ip -= sh;
     uint32_t bp = centerOff - kDescR * pitch - kDescR;                      // blurred window: rows/cols -18..18
     const unsigned shb = bp & 3u; bp -= shb;
-    uint32_t wi[9], wb[12];
+    // three rows per pass: lane -> (row ri of the pass, dword ii) once, then one add per pass (27 lanes of the half busy on the 9-dword
+    // intensity rows, 30 on the 10-dword blurred rows; the last pass reads one or two rows below the window - inside the level's
+    // buffer, the keypoint being kEdge = 19 rows from the bottom and the buffer one row taller than the level - and drops them)
+    uint32_t wi[10], wb[13];
+    const unsigned si = min((unsigned)sl, 26u), ri = (si * 57u) >> 9, ii = si - 9u * ri;            // si / 9, si % 9
+    const unsigned sb = min((unsigned)sl, 29u), rb = (sb * 205u) >> 11, ib = sb - 10u * rb;         // sb / 10, sb % 10
+    const uint32_t step3 = 3u * (unsigned)pitch;
+    {
+        uint32_t o = ip + __umul24(ri, (unsigned)pitch) + 4 * ii;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const unsigned e = min(sl + 32u * t, 29u * 9u - 1u), r = e / 9u, i = e - 9u * r;
-        wi[t] = *(const uint32_t*)(pyrF + (ip + __umul24(r, (unsigned)pitch) + 4 * i));
+        for (int t = 0; t < 10; ++t) { wi[t] = *(const uint32_t*)(pyrF + o); o += step3; }
+        o = bp + __umul24(rb, (unsigned)pitch) + 4 * ib;
+#pragma unroll
+        for (int t = 0; t < 13; ++t) { wb[t] = *(const uint32_t*)(blurF + o); o += step3; }
     }
 #pragma unroll
-    for (int t = 0; t < 12; ++t) {
-        const unsigned e = min(sl + 32u * t, (unsigned)(kDescRows * kDescDw) - 1u), r = e / (unsigned)kDescDw, i = e - kDescDw * r;
-        wb[t] = *(const uint32_t*)(blurF + (bp + __umul24(r, (unsigned)pitch) + 4 * i));
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) if (sl + 32u * t < 29u * 9u) lp[sl + 32 * t] = wi[t];
+    for (int t = 0; t < 10; ++t) if (sl < 27 && (t < 9 || ri < 2)) lp[sl + 27 * t] = wi[t];
     int m01 = 0, m10 = 0;
     {
         const int r = min(sl, 28), v = r - 14;
@@ -953,10 +966,10 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
         }
         if (sl < 29) { m10 = (int)sj - 16 * (int)sv; m01 = v * (int)sv; }
     }
-    m01 = half_sum(m01); m10 = half_sum(m10);
+    m01 = half_sum(m01, half); m10 = half_sum(m10, half);
     // the intensity rows have been consumed (LDS operations of a wave complete in order): reuse the region
 #pragma unroll
-    for (int t = 0; t < 12; ++t) if (sl + 32u * t < (unsigned)(kDescRows * kDescDw)) lp[sl + 32 * t] = wb[t];
+    for (int t = 0; t < 13; ++t) if (sl < 30 && (t < 12 || rb == 0)) lp[sl + 30 * t] = wb[t];
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     // descriptor
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
