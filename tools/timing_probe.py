@@ -5,12 +5,13 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 import ssvio_amd
 from ssvio_amd import synth
-B = 64
+BATCHES = [int(a) for a in sys.argv[1:]] or [1, 8, 64]
+B = max(BATCHES)
 frames = synth.frame_stream(1000, B, 480, 640)
 d = torch.from_numpy(frames).cuda()
 ex = ssvio_amd.ORBextractor(1000, 1.2, 8, 20, 7)
 fm = ssvio_amd.FeatureMatching(None, {})
-for b in (1, 8, 64):
+for b in BATCHES:
     pairs = np.array([[f, (f - 1) % b] for f in range(b)], np.int32)
     def step():
         ex.extract_batch_dev(d, b, 640, 480)
