@@ -155,6 +155,20 @@ void ssvio_matcher_destroy(ssvio_matcher* m);
  * calls are made on the handle; ssvio_matcher_destroy itself does not touch a borrowed stream (it waits for the device),
  * so the stream's owner -- often the extractor, ssvio_orb_get_stream -- may be destroyed before the matcher. */
 int  ssvio_matcher_set_stream(ssvio_matcher* m, void* hip_stream);
+/* Which kernel computes ComputeMatchingScore + the best / second-best search (src/FeatureMatching.cpp:211-228, :85-102) for the
+ * shapes beyond one small pair (the batched entry points; single pairs above 2048 x 4096 rows).  Both give identical results:
+ *   SSVIO_KERNEL_VALU (default): k_hamming_knn2, v_xor + v_bcnt per dword, the kernel north_star describes;
+ *   SSVIO_KERNEL_MFMA: k_hamming_knn2_mfma, the same distance as an exact int8 contraction on the matrix cores
+ *     (v_mfma_i32_32x32x32_i8; hamming = |a| - sum a_k t_k with the bits as +-1 / 0-1 integers), the accumulator doubling as the
+ *     (distance, train row) sort key.
+ *   SSVIO_KERNEL_MFMA_ALL: the matrix-core kernel for every shape, small single pairs included (those otherwise keep their own
+ *     one-launch kernel, k_hamming_knn2_small, which is the faster one there); for tests and measurements.
+ * The environment variable SSVIO_MATCH_KERNEL=mfma (mfma_all) makes that the default of new handles. */
+#define SSVIO_KERNEL_VALU 0
+#define SSVIO_KERNEL_MFMA 1
+#define SSVIO_KERNEL_MFMA_ALL 2
+int  ssvio_matcher_set_kernel(ssvio_matcher* m, int kernel);
+int  ssvio_matcher_get_kernel(ssvio_matcher* m, int* kernel);
 int  ssvio_matcher_set_profiling(ssvio_matcher* m, int enable);
 int  ssvio_matcher_kernel_times(ssvio_matcher* m, const char** names, double* total_ms, int32_t* launches, int cap, int* count);
 int  ssvio_matcher_profile_only(ssvio_matcher* m, const char* kernel);

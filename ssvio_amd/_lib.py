@@ -15,6 +15,7 @@ MAX_LEVELS = 16
 MODE_BRUTEFORCE, MODE_KNN2_RATIO, MODE_CROSSCHECK, MODE_CROSSCHECK_CV = 0, 1, 2, 4
 NOALLOC_SCRATCH_BYTES = 32 << 20
 PAIR_ID_SEQUENTIAL, PAIR_ID_TRIANGULAR = 0, 1
+KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_ALL = 0, 1, 2
 REC_DTYPE = np.dtype([("pair", "<i4"), ("n_matches", "<i4"), ("sum_dist", "<i8")])   # ssvio_pair_summary
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
@@ -77,6 +78,8 @@ SYMBOLS = {
     "ssvio_matcher_create": (_i, [_i, _f, _i, _vp]),
     "ssvio_matcher_destroy": (None, [_vp]),
     "ssvio_matcher_set_stream": (_i, [_vp, _vp]),
+    "ssvio_matcher_set_kernel": (_i, [_vp, _i]),
+    "ssvio_matcher_get_kernel": (_i, [_vp, _vp]),
     "ssvio_matcher_set_profiling": (_i, [_vp, _i]),
     "ssvio_matcher_kernel_times": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "ssvio_match_bruteforce": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp]),

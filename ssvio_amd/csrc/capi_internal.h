@@ -64,6 +64,7 @@ struct ssvio_matcher {
     std::vector<uint8_t> stageQ, stageT;              // packed copies of strided descriptor rows
     std::vector<int32_t> h_pairs;                     // what d_pairs holds (an unchanged pair list is not uploaded again)
     KernelProfiler prof; std::string profOnly;
+    int kernel = 0;                                   // SSVIO_KERNEL_VALU / SSVIO_KERNEL_MFMA: which 2-NN kernel the batched shapes run
     int lastPairs = 0, lastMaxRows = 0; bool lastHadPairs = false;    // the last batched call: d_out / d_nout hold lastPairs lists; d_pairs is its pair list
 };
 
@@ -111,8 +112,8 @@ int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs);           
 // larger ones are copied into d_q / d_t (capi_match.hip)
 int stage_pair(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, const uint8_t** d_q, const uint8_t** d_t);
 // the batched matcher in two steps, shared by the allocating entry points and the one that allocates nothing (capi_match.hip)
-struct MatchPlan { int maxRows, nChunks, chunkRows, nChunksR, chunkRowsR; bool small, smallRev; size_t partialEntries, partialRevEntries; };
-int match_plan(int maxQ, int maxT, int npairs, int mode, size_t limitEntries, MatchPlan& p);
+struct MatchPlan { int maxRows, nChunks, chunkRows, nChunksR, chunkRowsR; bool small, smallRev, mfma; size_t partialEntries, partialRevEntries; };
+int match_plan(int maxQ, int maxT, int npairs, int mode, int kernel, size_t limitEntries, MatchPlan& p);
 int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
                  const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts, const int* d_pairs, int npairs, int maxQ, int maxT, int mode,
                  uint2* partial, uint2* partialRev, ssvio_dmatch* out, int* nout, int32_t* raw, bool profile);

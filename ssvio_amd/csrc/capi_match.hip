@@ -19,8 +19,20 @@ int upload_rows(uint8_t* dst, const uint8_t* src, int n, int stride, std::vector
 // the chunk count -- not the chunk size -- is what this fixes; chunkRows is the upper bound for the partial lists' layout.
 // Query rows: a set handed over by the extractor holds up to 32 rows less than it can (the quadtree's overshoot slack); counting
 // query blocks without that slack keeps a block that will be empty out of the balance.
-static void pick_chunks(int maxQ, int maxT, int npairs, int& nChunks, int& chunkRows)
+static void pick_chunks(int maxQ, int maxT, int npairs, bool mfma, int& nChunks, int& chunkRows)
 {
+    if (mfma) {
+        // k_hamming_knn2_mfma: a workgroup expands its query rows into registers once (~100 instructions per 32 rows) and a chunk holds
+        // at most kMfmaChunkRows rows; ~1024 workgroups (two per CU, two rounds) of at least 256 train rows each
+        static const int targetM = [] { const char* e = getenv("SSVIO_MFMA_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+        const long qBlocks = (long)knn2_mfma_query_blocks(maxQ) * npairs;
+        long want = (targetM + qBlocks / 2) / qBlocks;
+        const long minChunks = (maxT + kMfmaChunkRows - 1) / kMfmaChunkRows, maxChunks = std::max<long>(minChunks, std::min<long>(64, maxT / 256));
+        want = std::max(minChunks, std::min(want, maxChunks));
+        nChunks = (int)std::max<long>(want, 1);
+        chunkRows = ((maxT + nChunks - 1) / nChunks + 31) / 32 * 32;
+        return;
+    }
     static const int forcedRows = [] { const char* e = getenv("SSVIO_MATCH_CHUNKROWS"); return e ? atoi(e) : 0; }();   // tuning knob
     static const int target = [] { const char* e = getenv("SSVIO_MATCH_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
     const long qBlocks = (long)knn2_query_blocks(maxQ) * npairs;
@@ -47,32 +59,39 @@ int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs)
 // how a batch of pairs is cut into launches: chunks of the train set (forward pass; reverse pass of the cross-check) and the
 // partial-list entries (uint2) they need.  limitEntries > 0 caps the scratch (the no-allocation entry point): chunks are
 // halved until both lists fit, SSVIO_ERR_CAPACITY if one chunk per pair does not.
-int match_plan(int maxQ, int maxT, int npairs, int mode, size_t limitEntries, MatchPlan& p)
+int match_plan(int maxQ, int maxT, int npairs, int mode, int kernel, size_t limitEntries, MatchPlan& p)
 {
     p.maxRows = std::max(maxQ, maxT);
-    pick_chunks(maxQ, maxT, npairs, p.nChunks, p.chunkRows);
-    p.small = knn2_small_applies(maxQ, maxT, npairs); p.smallRev = false;
+    p.mfma = kernel == SSVIO_KERNEL_MFMA || kernel == SSVIO_KERNEL_MFMA_ALL;
+    const bool smallOk = kernel != SSVIO_KERNEL_MFMA_ALL;
+    pick_chunks(maxQ, maxT, npairs, p.mfma, p.nChunks, p.chunkRows);
+    p.small = smallOk && knn2_small_applies(maxQ, maxT, npairs); p.smallRev = false;
     if (p.small) { p.nChunks = 1; p.chunkRows = maxT; }
     p.nChunksR = 0; p.chunkRowsR = 0;
     const bool rev = mode == SSVIO_MODE_CROSSCHECK || mode == SSVIO_MODE_CROSSCHECK_CV;
     if (mode == SSVIO_MODE_CROSSCHECK_CV) { p.nChunks = 1; p.chunkRows = maxT; p.small = false; }     // no forward search: the forward list holds the votes
     if (rev) {
-        pick_chunks(maxT, maxQ, npairs, p.nChunksR, p.chunkRowsR);
-        p.smallRev = knn2_small_applies(maxT, maxQ, npairs);
+        pick_chunks(maxT, maxQ, npairs, p.mfma, p.nChunksR, p.chunkRowsR);
+        p.smallRev = smallOk && knn2_small_applies(maxT, maxQ, npairs);
         if (p.smallRev) { p.nChunksR = 1; p.chunkRowsR = maxQ; }
     }
     const size_t per = (size_t)npairs * p.maxRows;
     if (limitEntries) {
         const size_t lim = rev ? limitEntries / 2 : limitEntries;
         if (per > lim) { set_error("%d pairs x %d rows need %zu bytes of scratch, the fixed scratch holds %zu", npairs, p.maxRows, per * 8 * (rev ? 2 : 1), limitEntries * 8); return SSVIO_ERR_CAPACITY; }
+        const int gran = p.mfma ? 32 : 8;
         auto fit = [&](int& nChunks, int& chunkRows, int rowsT) {
             if ((size_t)nChunks * per <= lim) return;
             const int want = (int)(lim / per);
-            chunkRows = ((rowsT + want - 1) / want + 7) / 8 * 8;
+            chunkRows = ((rowsT + want - 1) / want + gran - 1) / gran * gran;
             nChunks = std::max(1, (rowsT + chunkRows - 1) / chunkRows);
         };
         fit(p.nChunks, p.chunkRows, maxT);
         if (rev) fit(p.nChunksR, p.chunkRowsR, maxQ);
+        if (p.mfma && ((!p.small && mode != SSVIO_MODE_CROSSCHECK_CV && p.chunkRows > kMfmaChunkRows) || (rev && !p.smallRev && p.chunkRowsR > kMfmaChunkRows))) {
+            set_error("%d pairs x %d rows: the fixed scratch leaves chunks of more than %d train rows, beyond the MFMA kernel", npairs, p.maxRows, kMfmaChunkRows);
+            return SSVIO_ERR_CAPACITY;
+        }
     }
     p.partialEntries = (size_t)p.nChunks * per; p.partialRevEntries = (size_t)p.nChunksR * per;
     return SSVIO_OK;
@@ -93,7 +112,7 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
     a.nChunks = p.nChunks; a.chunkRows = p.chunkRows; a.partial = partial; a.maxRows = p.maxRows;
     if (mode != SSVIO_MODE_CROSSCHECK_CV) {
         ProfScope ps(prof, "k_hamming_knn2", s);
-        if (p.small) launch_knn2_small(a, maxQ, npairs, s); else launch_knn2(a, maxQ, npairs, s);
+        if (p.small) launch_knn2_small(a, maxQ, npairs, s); else if (p.mfma) launch_knn2_mfma(a, maxQ, npairs, s); else launch_knn2(a, maxQ, npairs, s);
         SSVIO_HIP(hipGetLastError());
     }
     FinalizeArgs f{};
@@ -109,7 +128,7 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
         r.nChunks = p.nChunksR; r.chunkRows = p.chunkRowsR; r.partial = partialRev;
         {
             ProfScope ps(prof, "k_hamming_knn2", s);
-            if (p.smallRev) launch_knn2_small(r, maxT, npairs, s); else launch_knn2(r, maxT, npairs, s);
+            if (p.smallRev) launch_knn2_small(r, maxT, npairs, s); else if (p.mfma) launch_knn2_mfma(r, maxT, npairs, s); else launch_knn2(r, maxT, npairs, s);
             SSVIO_HIP(hipGetLastError());
         }
         f.partialRev = partialRev; f.nChunksRev = p.nChunksR;
@@ -130,7 +149,7 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
 {
     hipStream_t s = m->stream;
     MatchPlan p;
-    int rc = match_plan(maxQ, maxT, npairs, mode, 0, p); if (rc) return rc;
+    int rc = match_plan(maxQ, maxT, npairs, mode, m->kernel, 0, p); if (rc) return rc;
     rc = grow(m->d_partial, m->partialCap, p.partialEntries, s); if (rc) return rc;
     rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
     if (mode == 3) { rc = grow(m->d_raw, m->rawCap, (size_t)npairs * 3 * p.maxRows, s); if (rc) return rc; }
@@ -233,6 +252,7 @@ int ssvio_matcher_create(int threshold, float nn_ratio, int device, ssvio_matche
     SSVIO_HIP(hipSetDevice(device));
     ssvio_matcher* m = new ssvio_matcher();
     m->device = device; m->threshold = threshold; m->nnRatio = nn_ratio;
+    { const char* e = getenv("SSVIO_MATCH_KERNEL"); m->kernel = (e && strcmp(e, "mfma") == 0) ? SSVIO_KERNEL_MFMA : (e && strcmp(e, "mfma_all") == 0) ? SSVIO_KERNEL_MFMA_ALL : SSVIO_KERNEL_VALU; }
     if (hipStreamCreateWithFlags(&m->own, hipStreamNonBlocking) != hipSuccess || hipMalloc(&m->d_counts2, 2 * sizeof(int)) != hipSuccess ||
         hipHostMalloc((void**)&m->h_counts2, 2 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&m->d_counts2m, m->h_counts2, 0) != hipSuccess) {
@@ -273,6 +293,22 @@ int ssvio_matcher_set_stream(ssvio_matcher* m, void* hip_stream)
     SSVIO_HIP(hipSetDevice(m->device));
     SSVIO_HIP(hipStreamSynchronize(m->stream));
     m->stream = hip_stream ? (hipStream_t)hip_stream : m->own;
+    return SSVIO_OK;
+}
+
+int ssvio_matcher_set_kernel(ssvio_matcher* m, int kernel)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (kernel != SSVIO_KERNEL_VALU && kernel != SSVIO_KERNEL_MFMA && kernel != SSVIO_KERNEL_MFMA_ALL) { set_error("kernel must be SSVIO_KERNEL_VALU, _MFMA or _MFMA_ALL"); return SSVIO_ERR_INVALID; }
+    m->kernel = kernel;
+    return SSVIO_OK;
+}
+
+int ssvio_matcher_get_kernel(ssvio_matcher* m, int* kernel)
+{
+    if (mt_check(m)) return SSVIO_ERR_INVALID;
+    if (!kernel) { set_error("null argument"); return SSVIO_ERR_INVALID; }
+    *kernel = m->kernel;
     return SSVIO_OK;
 }
 

@@ -264,6 +264,17 @@ class FeatureMatching:
         L.check(L.lib().ssvio_match_batch_fetch(self._h, npairs, max_rows, L.ptr(out), L.ptr(n)))
         return out, n
 
+    def set_kernel(self, kernel):
+        """which 2-NN kernel the batched shapes run: "valu" (k_hamming_knn2, default) or "mfma" (k_hamming_knn2_mfma); "mfma_all":
+        the latter for small single pairs too.  Same results."""
+        k = {"valu": L.KERNEL_VALU, "mfma": L.KERNEL_MFMA, "mfma_all": L.KERNEL_MFMA_ALL}.get(kernel, kernel)
+        L.check(L.lib().ssvio_matcher_set_kernel(self._h, int(k)))
+
+    def get_kernel(self):
+        k = C.c_int(0)
+        L.check(L.lib().ssvio_matcher_get_kernel(self._h, C.byref(k)))
+        return {L.KERNEL_MFMA: "mfma", L.KERNEL_MFMA_ALL: "mfma_all"}.get(k.value, "valu")
+
     def set_profiling(self, on): L.check(L.lib().ssvio_matcher_set_profiling(self._h, int(on)))
     def kernel_times(self): return L.kernel_times(L.lib().ssvio_matcher_kernel_times, self._h)
     def profile_only(self, kernel): L.check(L.lib().ssvio_matcher_profile_only(self._h, kernel.encode() if kernel else None))
