@@ -110,9 +110,12 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
     a.qSetStrideRows = qStrideRows; a.tSetStrideRows = tStrideRows;
     a.qcounts = d_qcounts; a.tcounts = d_tcounts; a.pairs = d_pairs; a.swap = 0;
     a.nChunks = p.nChunks; a.chunkRows = p.chunkRows; a.partial = partial; a.maxRows = p.maxRows;
+    // the second-best distance is only read by the ratio test (mode 1) and the raw output (mode 3); MatchByBruteForce
+    // (src/FeatureMatching.cpp:30-54) and the cross-checks use the nearest neighbour alone
+    const bool needSecond = mode == SSVIO_MODE_KNN2_RATIO || mode == 3;
     if (mode != SSVIO_MODE_CROSSCHECK_CV) {
         ProfScope ps(prof, "k_hamming_knn2", s);
-        if (p.small) launch_knn2_small(a, maxQ, npairs, s); else if (p.mfma) launch_knn2_mfma(a, maxQ, npairs, s); else launch_knn2(a, maxQ, npairs, s);
+        if (p.small) launch_knn2_small(a, maxQ, npairs, s); else if (p.mfma) launch_knn2_mfma(a, maxQ, npairs, needSecond, s); else launch_knn2(a, maxQ, npairs, s);
         SSVIO_HIP(hipGetLastError());
     }
     FinalizeArgs f{};
@@ -128,7 +131,7 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
         r.nChunks = p.nChunksR; r.chunkRows = p.chunkRowsR; r.partial = partialRev;
         {
             ProfScope ps(prof, "k_hamming_knn2", s);
-            if (p.smallRev) launch_knn2_small(r, maxT, npairs, s); else if (p.mfma) launch_knn2_mfma(r, maxT, npairs, s); else launch_knn2(r, maxT, npairs, s);
+            if (p.smallRev) launch_knn2_small(r, maxT, npairs, s); else if (p.mfma) launch_knn2_mfma(r, maxT, npairs, false, s); else launch_knn2(r, maxT, npairs, s);
             SSVIO_HIP(hipGetLastError());
         }
         f.partialRev = partialRev; f.nChunksRev = p.nChunksR;

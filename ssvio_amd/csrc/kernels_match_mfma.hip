@@ -74,7 +74,56 @@ __device__ __forceinline__ void stage_write(v4i* frag, int row, int half, const 
     }
 }
 
-template <int G, int MINW>
+__device__ __forceinline__ int imin3(int a, int b, int c)
+{
+    int r;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// the two smallest of {m1 <= m2} and a tile's 16 accumulators of one query column: two values per step --
+// second smallest of {m1, m2, a, b} = min(m2, second smallest of {m1, a, b}) because m1 <= m2 -- 1.5 instructions per value
+__device__ __forceinline__ void select16(int& m1, int& m2, const v16i acc)
+{
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        m2 = min(m2, imed3(m1, acc[r], acc[r + 1]));
+        m1 = imin3(m1, acc[r], acc[r + 1]);
+    }
+    m1 -= 32; m2 -= 32;
+}
+
+// nearest neighbour only (the filters of modes 0, 2 and 4 never read the second key): one v_min3 per two values
+__device__ __forceinline__ void select16_first(int& m1, const v16i acc)
+{
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) m1 = imin3(m1, acc[r], acc[r + 1]);
+    m1 -= 32;
+}
+
+// the same for the last tile of a chunk: rows at or beyond `left` do not exist
+__device__ __forceinline__ void select16_ragged(int& m1, int& m2, const v16i acc, int h, int left)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int v = (8 * (r >> 2) + 4 * h + (r & 3)) < left ? acc[r] : kMSent;
+        m2 = imed3(m1, m2, v); m1 = min(m1, v);
+    }
+    m1 -= 32; m2 -= 32;
+}
+
+// one dword of a thread's 16 bytes of a train row -> two 16-byte fragment pieces (lane halves 0 and 1 of k-step s)
+__device__ __forceinline__ void stage_write_dword(v4i* frag, int row, int s, uint32_t d)
+{
+    v4i* p = frag + ((row >> 5) * 8 + s) * 64 + (row & 31);
+    p[0] = expand_train(d & 0xFFFFu);
+    p[32] = expand_train(d >> 16);
+}
+
+// Software-pipelined: the matrix instructions of tile t are issued between the selection instructions of tile t - 1
+// (two accumulator sets), and a quarter of the next stage's bit expansion rides along with every tile, so that one
+// wave keeps both the matrix pipe and the vector ALU busy instead of alternating between them.
+template <int G, int MINW, bool SECOND>
 __global__ __launch_bounds__(256, MINW) void k_hamming_knn2_mfma(MatchArgs a)
 {
     __shared__ v4i frag[2][(kMStage / 32) * 8 * 64];            // 2 x 32 KB
@@ -89,8 +138,10 @@ __global__ __launch_bounds__(256, MINW) void k_hamming_knn2_mfma(MatchArgs a)
     // the rows the set really holds, split evenly over the chunks (a.chunkRows: the host's upper bound, <= kMfmaChunkRows)
     const int rowsPer = min(a.chunkRows, ((nt + a.nChunks - 1) / a.nChunks + 31) & ~31);
     const int cBegin = min(nt, chunk * rowsPer), cEnd = min(nt, cBegin + rowsPer);
+    const int nTiles = (cEnd - cBegin + 31) >> 5;
     uint2* out = a.partial + ((size_t)pair * a.nChunks + chunk) * a.maxRows;
     constexpr int QWG = 4 * G * 32;
+    const int srow = tid >> 1, shalf = tid & 1;                  // this thread's share of a stage: 16 bytes of row srow
 
     // accumulator start: the row field of this lane's 16 rows of a tile
     v16i C;
@@ -111,55 +162,63 @@ __global__ __launch_bounds__(256, MINW) void k_hamming_knn2_mfma(MatchArgs a)
             for (int s = 0; s < 8; ++s) { B[g][s] = expand_query(h ? q[s] >> 16 : q[s] & 0xFFFFu); n += __popc(q[s]); }
             na[g] = n; m1[g] = kMSent; m2[g] = kMSent;
         }
-        int buf = 0;
+        // stage `st` holds rows cBegin + 128 st ...; a thread's 16 bytes of it (zeros beyond the chunk)
+        auto load_stage = [&](int st) {
+            const int r0 = cBegin + st * kMStage;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r0 + srow < cEnd) v = T[(size_t)r0 * 2 + tid];
+            return v;
+        };
         __syncthreads();                                          // (a second query tile: the previous one is done with the buffers)
-        if (cBegin < cEnd) {
-            const int rows = min(kMStage, cEnd - cBegin);
-            if (tid < rows * 2) stage_write(frag[0], tid >> 1, tid & 1, T[(size_t)cBegin * 2 + tid]);
+        if (nTiles > 0) {
+            const uint4 v = load_stage(0);
+            stage_write_dword(frag[0], srow, 4 * shalf + 0, v.x); stage_write_dword(frag[0], srow, 4 * shalf + 1, v.y);
+            stage_write_dword(frag[0], srow, 4 * shalf + 2, v.z); stage_write_dword(frag[0], srow, 4 * shalf + 3, v.w);
         }
+        uint4 pre = load_stage(1), pre2 = make_uint4(0, 0, 0, 0);           // the stage being expanded, the one behind it in flight
         __syncthreads();
-        for (int t0 = cBegin; t0 < cEnd; t0 += kMStage) {
-            const int rows = min(kMStage, cEnd - t0);
-            const int nextRows = min(kMStage, cEnd - (t0 + kMStage));
-            uint4 pre = make_uint4(0, 0, 0, 0);
-            if (tid < nextRows * 2) pre = T[(size_t)(t0 + kMStage) * 2 + tid];
-            const int ntiles = (rows + 31) >> 5;
-            for (int tile = 0; tile < ntiles; ++tile) {
-                const v4i* fp = frag[buf] + tile * 8 * 64 + lane;
-                v16i acc[G];
+
+        // tile tt: its matrix instructions into `cmp`; tile tt - 1 (always a full tile) selected out of `sel`
+        auto step = [&](v16i (&cmp)[G], v16i (&sel)[G], int tt, bool doSel) {
+            const int i = tt & 3, st = tt >> 2;
+            if (i == 0) pre2 = load_stage(st + 2);
+            const v4i* fp = frag[st & 1] + i * 8 * 64 + lane;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const v4i A = fp[s * 64];
+            for (int s = 0; s < 8; ++s) {
+                const v4i A = fp[s * 64];
 #pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[g][s], s == 0 ? C : acc[g], 0, 0, 0);
-                }
-                const int left = cEnd - (t0 + tile * 32);         // valid rows of this tile, wave-uniform
-                if (left >= 32) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) { m2[g] = imed3(m1[g], m2[g], acc[g][r]); m1[g] = min(m1[g], acc[g][r]); }
-                        m1[g] -= 32; m2[g] -= 32;
-                    }
-                } else {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int v = (8 * (r >> 2) + 4 * h + (r & 3)) < left ? acc[g][r] : kMSent;
-                            m2[g] = imed3(m1[g], m2[g], v); m1[g] = min(m1[g], v);
-                        }
-                        m1[g] -= 32; m2[g] -= 32;
-                    }
-                }
+                for (int g = 0; g < G; ++g)
+                    cmp[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[g][s], s == 0 ? C : cmp[g], 0, 0, 0);
             }
-            if (tid < nextRows * 2) stage_write(frag[buf ^ 1], tid >> 1, tid & 1, pre);
-            __syncthreads();
-            buf ^= 1;
+            if (doSel) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) { if (SECOND) select16(m1[g], m2[g], sel[g]); else select16_first(m1[g], sel[g]); }
+            }
+            // a quarter of the next stage's expansion
+            if (cBegin + (st + 1) * kMStage + srow < cEnd) {
+                const uint32_t d = i == 0 ? pre.x : i == 1 ? pre.y : i == 2 ? pre.z : pre.w;
+                stage_write_dword(frag[(st + 1) & 1], srow, 4 * shalf + i, d);
+            }
+            if (i == 3) { pre = pre2; __syncthreads(); }
+        };
+
+        v16i X[G], Y[G];
+        if (nTiles > 0) {
+            step(X, Y, 0, false);
+            int tt = 1;
+            for (; tt + 1 < nTiles; tt += 2) { step(Y, X, tt, true); step(X, Y, tt + 1, true); }
+            const int left = cEnd - (cBegin + (nTiles - 1) * 32);     // rows of the last tile
+            if (tt < nTiles) {
+                step(Y, X, tt, true);
+#pragma unroll
+                for (int g = 0; g < G; ++g) { if (left >= 32 && SECOND) select16(m1[g], m2[g], Y[g]); else select16_ragged(m1[g], m2[g], Y[g], h, left); }
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) { if (left >= 32 && SECOND) select16(m1[g], m2[g], X[g]); else select16_ragged(m1[g], m2[g], X[g], h, left); }
+            }
         }
         // back to the (dist << 23 | trainIdx) keys: the row field now counts from the end of the last tile
-        const int tEnd = cBegin + ((cEnd - cBegin + 31) & ~31);
+        const int tEnd = cBegin + nTiles * 32;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             uint32_t k[2];
@@ -172,20 +231,20 @@ __global__ __launch_bounds__(256, MINW) void k_hamming_knn2_mfma(MatchArgs a)
             // the other half-wave holds the same query's keys over the other 16 rows of every tile
             const uint32_t o1 = __shfl_xor(k[0], 32), o2 = __shfl_xor(k[1], 32);
             const uint32_t lo1 = min(k[0], o1), hi1 = max(k[0], o1);
-            const uint32_t k2 = min(hi1, min(k[1], o2));
+            const uint32_t k2 = SECOND ? min(hi1, min(k[1], o2)) : kKeyInit;
             const int qi = qtile + (wave * G + g) * 32 + col;
             if (h == 0 && qi < nq) out[qi] = make_uint2(lo1, k2);
         }
     }
 }
 
-// query groups of 32 per wave (tuning knob: SSVIO_MFMA_G).  3 groups = 384 query rows per workgroup in 244 registers: two
-// workgroups per CU, one wave's selection under the other's matrix instructions
+// query groups of 32 per wave (tuning knob: SSVIO_MFMA_G).  2 groups = 256 query rows per workgroup: two accumulator sets fit 226
+// registers without spills, two workgroups per CU
 int knn2_mfma_groups(int maxQ)
 {
     static const int forced = [] { const char* e = getenv("SSVIO_MFMA_G"); return e ? atoi(e) : 0; }();
     if (forced >= 1 && forced <= 4) return forced;
-    return maxQ > 256 ? 3 : maxQ > 128 ? 2 : 1;
+    return maxQ > 128 ? 2 : 1;
 }
 
 int knn2_mfma_query_blocks(int maxQ)
@@ -194,16 +253,21 @@ int knn2_mfma_query_blocks(int maxQ)
     return (std::max(maxQ - 32, 1) + qwg - 1) / qwg;
 }
 
-void launch_knn2_mfma(const MatchArgs& a, int maxQ, int npairs, hipStream_t s)
+template <bool SECOND>
+static void launch_mfma_g(const MatchArgs& a, int G, dim3 grid, hipStream_t s)
+{
+    if (G == 4) hipLaunchKernelGGL((k_hamming_knn2_mfma<4, 1, SECOND>), grid, dim3(256), 0, s, a);
+    else if (G == 3) hipLaunchKernelGGL((k_hamming_knn2_mfma<3, 2, SECOND>), grid, dim3(256), 0, s, a);
+    else if (G == 2) hipLaunchKernelGGL((k_hamming_knn2_mfma<2, 2, SECOND>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_hamming_knn2_mfma<1, 2, SECOND>), grid, dim3(256), 0, s, a);
+}
+
+// needSecond = false: only the nearest neighbour is searched (the second key of every partial entry is kKeyInit)
+void launch_knn2_mfma(const MatchArgs& a, int maxQ, int npairs, bool needSecond, hipStream_t s)
 {
     const int G = knn2_mfma_groups(maxQ);
     dim3 grid(knn2_mfma_query_blocks(maxQ), a.nChunks, npairs);
-    static const bool g4two = getenv("SSVIO_MFMA_G4_TWO") != nullptr;      // G = 4 squeezed into 256 registers (spills) for two waves per SIMD
-    if (G == 4 && g4two) hipLaunchKernelGGL((k_hamming_knn2_mfma<4, 2>), grid, dim3(256), 0, s, a);
-    else if (G == 4) hipLaunchKernelGGL((k_hamming_knn2_mfma<4, 1>), grid, dim3(256), 0, s, a);
-    else if (G == 3) hipLaunchKernelGGL((k_hamming_knn2_mfma<3, 2>), grid, dim3(256), 0, s, a);
-    else if (G == 2) hipLaunchKernelGGL((k_hamming_knn2_mfma<2, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_hamming_knn2_mfma<1, 2>), grid, dim3(256), 0, s, a);
+    if (needSecond) launch_mfma_g<true>(a, G, grid, s); else launch_mfma_g<false>(a, G, grid, s);
 }
 
 }  // namespace ssvio

@@ -118,7 +118,7 @@ int  knn2_queries_per_lane(int maxQ);       // R of k_hamming_knn2<R> for this m
 void launch_finalize(const FinalizeArgs& a, int npairs, int maxQ, int maxT, hipStream_t s);
 // the same 2-NN on the matrix cores (kernels_match_mfma.hip): exact int8 contraction, selectable per handle
 constexpr int kMfmaChunkRows = 8160;        // most train rows a chunk of k_hamming_knn2_mfma can hold (13-bit row field, 32-row tiles)
-void launch_knn2_mfma(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);
+void launch_knn2_mfma(const MatchArgs& a, int maxQ, int npairs, bool needSecond, hipStream_t s);   // needSecond = false: nearest neighbour only
 int  knn2_mfma_query_blocks(int maxQ);      // grid.x of k_hamming_knn2_mfma for sets of up to maxQ rows
 
 #if defined(__HIPCC__)

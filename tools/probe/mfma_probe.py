@@ -14,21 +14,21 @@ if len(sys.argv) > 1:
         c = torch.from_numpy(counts).cuda()
         pairs = np.array([[(f + 1) % nsets, f % nsets] for f in range(npairs)], np.int32)
         pe = float((counts[pairs[:, 0]].astype(np.float64) * counts[pairs[:, 1]]).sum())
-        for kernel in ("valu", "mfma"):
+        for kernel, mode in (("valu", 0), ("mfma", 0), ("mfma", 1)):
             fm = ssvio_amd.FeatureMatching(None, {})
             fm.set_kernel(kernel)
-            for _ in range(3): fm.match_batch_dev(d, cap, cap, c, pairs, 0)
+            for _ in range(3): fm.match_batch_dev(d, cap, cap, c, pairs, mode)
             fm.sync(); fm.set_profiling(True)
             n = 20
-            for _ in range(n): fm.match_batch_dev(d, cap, cap, c, pairs, 0)
+            for _ in range(n): fm.match_batch_dev(d, cap, cap, c, pairs, mode)
             fm.sync()
             t = fm.kernel_times()
             us = {k: v[0] * 1e3 / v[1] for k, v in t.items()}
-            print("%-22s %-16s %-5s knn2 %9.2f us  finalize(+merge) %7.2f us  -> %.3e pairs/s" % (sys.argv[1], name, kernel, us["k_hamming_knn2"], us["k_match_finalize"],
+            print("%-22s %-16s %-5s mode %d knn2 %9.2f us  finalize(+merge) %7.2f us  -> %.3e pairs/s" % (sys.argv[1], name, kernel, mode, us["k_hamming_knn2"], us["k_match_finalize"],
                   pe / (us["k_hamming_knn2"] * 1e-6)), flush=True)
             fm.close()
 else:
-    for env in ({}, {"SSVIO_MFMA_G": "2"}, {"SSVIO_MFMA_G": "4"}, {"SSVIO_MFMA_G": "4", "SSVIO_MFMA_G4_TWO": "1"}, {"SSVIO_MFMA_BLOCKS": "512"}, {"SSVIO_MFMA_BLOCKS": "2048"}):
+    for env in ({}, {"SSVIO_MFMA_G": "3"}, {"SSVIO_MFMA_G": "4"}, {"SSVIO_MFMA_BLOCKS": "512"}, {"SSVIO_MFMA_BLOCKS": "2048"}):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, __file__, " ".join("%s=%s" % (k.replace("SSVIO_MFMA_", ""), v) for k, v in env.items()) or "default"], env=e, capture_output=True, text=True, timeout=200)
         print(r.stdout.strip() or r.stderr[-600:], flush=True)
