@@ -22,6 +22,8 @@
 #include "match.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace ssvio {
 
@@ -30,13 +32,14 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int kMStage = 128;                 // train rows per LDS stage (4 tiles of 32)
 constexpr int kMFBase = 8160;                // row field of row 0 of the tile in flight (8160 + 31 < 8192)
-constexpr int kMSent = 0x3FFFFFFF;           // "no candidate": stays above every real key through all the -32 steps
+// The keys are kept as int32 values whose bit patterns are also positive normal floats (2.0 +- 2^21 ulps), so that the one
+// three-input median the compiler exposes as a builtin, v_med3_f32, orders them exactly like the integer instructions do.
+constexpr int kMBias = 0x40000000;
+constexpr int kMSent = 0x7F000000;           // "no candidate": stays above every real key through all the -32 steps
 
-__device__ __forceinline__ int imed3(int a, int b, int c)
+__device__ __forceinline__ int med3k(int a, int b, int c)
 {
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    return __float_as_int(__builtin_amdgcn_fmed3f(__int_as_float(a), __int_as_float(b), __int_as_float(c)));
 }
 
 // 4 bits -> 4 bytes: 0x80 where the bit is set (bit i lands on bit 8i + 7; the shifted copies do not overlap, so no carries)
@@ -60,58 +63,6 @@ __device__ __forceinline__ v4i expand_query(uint32_t bits16)
     return r;
 }
 
-// one thread's 16 bytes of a train row (dwords 4 * half .. 4 * half + 3) -> eight 16-byte fragment pieces in LDS
-__device__ __forceinline__ void stage_write(v4i* frag, int row, int half, const uint4 raw)
-{
-    const int tile = row >> 5, r = row & 31;
-    const uint32_t d[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int s = 4 * half + i;
-        v4i* p = frag + (tile * 8 + s) * 64 + r;
-        p[0] = expand_train(d[i] & 0xFFFFu);
-        p[32] = expand_train(d[i] >> 16);
-    }
-}
-
-__device__ __forceinline__ int imin3(int a, int b, int c)
-{
-    int r;
-    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// the two smallest of {m1 <= m2} and a tile's 16 accumulators of one query column: two values per step --
-// second smallest of {m1, m2, a, b} = min(m2, second smallest of {m1, a, b}) because m1 <= m2 -- 1.5 instructions per value
-__device__ __forceinline__ void select16(int& m1, int& m2, const v16i acc)
-{
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        m2 = min(m2, imed3(m1, acc[r], acc[r + 1]));
-        m1 = imin3(m1, acc[r], acc[r + 1]);
-    }
-    m1 -= 32; m2 -= 32;
-}
-
-// nearest neighbour only (the filters of modes 0, 2 and 4 never read the second key): one v_min3 per two values
-__device__ __forceinline__ void select16_first(int& m1, const v16i acc)
-{
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) m1 = imin3(m1, acc[r], acc[r + 1]);
-    m1 -= 32;
-}
-
-// the same for the last tile of a chunk: rows at or beyond `left` do not exist
-__device__ __forceinline__ void select16_ragged(int& m1, int& m2, const v16i acc, int h, int left)
-{
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int v = (8 * (r >> 2) + 4 * h + (r & 3)) < left ? acc[r] : kMSent;
-        m2 = imed3(m1, m2, v); m1 = min(m1, v);
-    }
-    m1 -= 32; m2 -= 32;
-}
-
 // one dword of a thread's 16 bytes of a train row -> two 16-byte fragment pieces (lane halves 0 and 1 of k-step s)
 __device__ __forceinline__ void stage_write_dword(v4i* frag, int row, int s, uint32_t d)
 {
@@ -120,12 +71,38 @@ __device__ __forceinline__ void stage_write_dword(v4i* frag, int row, int s, uin
     p[32] = expand_train(d >> 16);
 }
 
-// Software-pipelined: the matrix instructions of tile t are issued between the selection instructions of tile t - 1
-// (two accumulator sets), and a quarter of the next stage's bit expansion rides along with every tile, so that one
-// wave keeps both the matrix pipe and the vector ALU busy instead of alternating between them.
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), expanded at compile time
+template <class F, int... U>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, U...>) { (f(std::integral_constant<int, U>{}), ...); }
+
+// the last tile of a chunk, and the few tiles around it: the two smallest of {m1 <= m2} and a tile's 16 accumulators of one
+// query column; rows at or beyond `left` do not exist
+__device__ __forceinline__ void select16_ragged(int& m1, int& m2, const v16i acc, int h, int left)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int v = (8 * (r >> 2) + 4 * h + (r & 3)) < left ? acc[r] : kMSent;
+        m2 = med3k(m1, m2, v); m1 = min(m1, v);
+    }
+    m1 -= 32; m2 -= 32;
+}
+
+// The inner loop is written slot by slot, a slot being one matrix instruction and the vector work that is issued in its
+// shadow (32 cycles), with scheduling fences between the slots so that the order below is the order of the instruction stream:
+//   - the matrix instruction of k-step s of the chain (tile, query group g);
+//   - the read of the A fragment three slots ahead (a ring of four fragment registers);
+//   - two values (four in slot 1, none in slot 0) of the selection out of the accumulators of the chain BEFORE this one (group g - 1 of this tile, or the last
+//     group of the previous tile): the chains are skewed by one, so one accumulator set per group is enough and a wave keeps
+//     the matrix pipe and the vector ALU busy at the same time.  Second smallest of {m1, m2, a, b} = min(m2, second smallest
+//     of {m1, a, b}) because m1 <= m2: 1.5 instructions per value; 0.5 when only the nearest neighbour is asked for
+//     (SECOND = false: the filters of modes 0, 2 and 4 never read the second key);
+//   - every G-th slot, one nibble of the thread's share of the next stage's bit expansion.
+// Two waves per SIMD that each alternate between a matrix phase and a vector phase fall into step and leave each pipe idle
+// half of the time; this order does not.
 template <int G, int MINW, bool SECOND>
 __global__ __launch_bounds__(256, MINW) void k_hamming_knn2_mfma(MatchArgs a)
 {
+    static_assert(G >= 2, "the chain being selected and the chain being computed need different accumulators");
     __shared__ v4i frag[2][(kMStage / 32) * 8 * 64];            // 2 x 32 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -141,12 +118,13 @@ __global__ __launch_bounds__(256, MINW) void k_hamming_knn2_mfma(MatchArgs a)
     const int nTiles = (cEnd - cBegin + 31) >> 5;
     uint2* out = a.partial + ((size_t)pair * a.nChunks + chunk) * a.maxRows;
     constexpr int QWG = 4 * G * 32;
-    const int srow = tid >> 1, shalf = tid & 1;                  // this thread's share of a stage: 16 bytes of row srow
+    const int srow = tid & 127, shalf = tid >> 7;                // this thread's share of a stage: 16 bytes (half) of row srow
+    const int wofs = ((srow >> 5) * 8 + 4 * shalf) * 64 + (srow & 31);   // where its first fragment piece goes (v4i units)
 
     // accumulator start: the row field of this lane's 16 rows of a tile
     v16i C;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) C[r] = kMFBase + 8 * (r >> 2) + 4 * h + (r & 3);
+    for (int r = 0; r < 16; ++r) C[r] = kMBias + kMFBase + 8 * (r >> 2) + 4 * h + (r & 3);
 
     for (int qtile = blockIdx.x * QWG; qtile < nq; qtile += gridDim.x * QWG) {          // block-uniform
         v4i B[G][8];
@@ -162,59 +140,84 @@ __global__ __launch_bounds__(256, MINW) void k_hamming_knn2_mfma(MatchArgs a)
             for (int s = 0; s < 8; ++s) { B[g][s] = expand_query(h ? q[s] >> 16 : q[s] & 0xFFFFu); n += __popc(q[s]); }
             na[g] = n; m1[g] = kMSent; m2[g] = kMSent;
         }
-        // stage `st` holds rows cBegin + 128 st ...; a thread's 16 bytes of it (zeros beyond the chunk)
-        auto load_stage = [&](int st) {
-            const int r0 = cBegin + st * kMStage;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r0 + srow < cEnd) v = T[(size_t)r0 * 2 + tid];
-            return v;
-        };
+        if (nTiles <= 0) {                                        // block-uniform: an empty chunk still owes its (empty) lists
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int qi = qtile + (wave * G + g) * 32 + col;
+                if (h == 0 && qi < nq) out[qi] = make_uint2(kKeyInit, kKeyInit);
+            }
+            continue;
+        }
+        // a thread's 16 bytes of stage st (rows cBegin + 128 st ...).  Rows beyond the chunk are never selected (ragged last tile),
+        // so the address is only kept inside the set
+        auto load_stage = [&](int st) { return T[(size_t)min(cBegin + st * kMStage + srow, nt - 1) * 2 + shalf]; };
         __syncthreads();                                          // (a second query tile: the previous one is done with the buffers)
-        if (nTiles > 0) {
+        {
             const uint4 v = load_stage(0);
             stage_write_dword(frag[0], srow, 4 * shalf + 0, v.x); stage_write_dword(frag[0], srow, 4 * shalf + 1, v.y);
             stage_write_dword(frag[0], srow, 4 * shalf + 2, v.z); stage_write_dword(frag[0], srow, 4 * shalf + 3, v.w);
         }
-        uint4 pre = load_stage(1), pre2 = make_uint4(0, 0, 0, 0);           // the stage being expanded, the one behind it in flight
+        uint4 pre = load_stage(1), pre2 = pre;                    // the stage being expanded; the one behind it, in flight
         __syncthreads();
 
-        // tile tt: its matrix instructions into `cmp`; tile tt - 1 (always a full tile) selected out of `sel`
-        auto step = [&](v16i (&cmp)[G], v16i (&sel)[G], int tt, bool doSel) {
-            const int i = tt & 3, st = tt >> 2;
-            if (i == 0) pre2 = load_stage(st + 2);
-            const v4i* fp = frag[st & 1] + i * 8 * 64 + lane;
+        v16i acc[G];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const v4i A = fp[s * 64];
+        for (int r = 0; r < 16; ++r) acc[G - 1][r] = kMSent;      // "the chain before the first": selecting it changes nothing
+        // stages all of whose tiles are full and followed by another tile
+        const int nMain = (nTiles - 1) >> 2;
+        for (int st = 0; st < nMain; ++st) {
+            const v4i* fp = frag[st & 1] + lane;
+            v4i* wp = frag[(st + 1) & 1] + wofs;
+            pre2 = load_stage(st + 2);
+            const uint32_t pd[4] = {pre.x, pre.y, pre.z, pre.w};
+            v4i Ar[4];
+            Ar[0] = fp[0]; Ar[1] = fp[64]; Ar[2] = fp[128];
+            v4i piece;
+            static_for([&](auto uc) {                             // slot u = ((tile I) * G + g) * 8 + s
+                constexpr int u = decltype(uc)::value;
+                constexpr int I = u / (8 * G), g = (u / 8) % G, s = u % 8, v = u % (8 * G);
+                constexpr int p = (g + G - 1) % G;
+                __builtin_amdgcn_sched_barrier(0);
+                acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ar[u & 3], B[g][s], s == 0 ? C : acc[g], 0, 0, 0);
+                if (u + 3 < 32 * G) {
+                    constexpr int u3 = u + 3;
+                    Ar[u3 & 3] = fp[(u3 / (8 * G)) * 8 * 64 + (u3 % 8) * 64];
+                }
+                // (slot 0 of a chain selects nothing: the previous chain's last matrix instruction is still on its way)
+                constexpr int r0 = s == 0 ? 0 : s == 1 ? 0 : 2 * s, r1 = s == 0 ? 0 : 2 * s + 2;
 #pragma unroll
-                for (int g = 0; g < G; ++g)
-                    cmp[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[g][s], s == 0 ? C : cmp[g], 0, 0, 0);
-            }
-            if (doSel) {
+                for (int r = r0; r < r1; r += 2) {
+                    if (SECOND) m2[p] = min(m2[p], med3k(m1[p], acc[p][r], acc[p][r + 1]));
+                    m1[p] = min(min(m1[p], acc[p][r]), acc[p][r + 1]);
+                }
+                if (s == 7) { m1[p] -= 32; if (SECOND) m2[p] -= 32; }
+                if (v % G == 0) {                                 // nibble j of dword I of the thread's share of the next stage
+                    constexpr int j = v / G;
+                    piece[j & 3] = (int)spread4((pd[I] >> (4 * j)) & 15u);
+                    if ((j & 3) == 3) wp[I * 64 + (j >> 2) * 32] = piece;
+                }
+            }, std::make_integer_sequence<int, 32 * G>{});
+            __builtin_amdgcn_sched_barrier(0);
+            pre = pre2;
+            __syncthreads();
+        }
+        // the 1..4 tiles left, all in stage nMain; every tile before the last is full
+        {
+            // the chain still waiting for its selection (group G - 1 of the last tile above, or the sentinel chain)
+            if (SECOND) { select16_ragged(m1[G - 1], m2[G - 1], acc[G - 1], h, 32); }
+            else { int d = kMSent; select16_ragged(m1[G - 1], d, acc[G - 1], h, 32); }
+            for (int tt = nMain * 4; tt < nTiles; ++tt) {
+                const v4i* fp = frag[nMain & 1] + (tt & 3) * 8 * 64 + lane;
+                const int left = min(32, cEnd - (cBegin + tt * 32));
 #pragma unroll
-                for (int g = 0; g < G; ++g) { if (SECOND) select16(m1[g], m2[g], sel[g]); else select16_first(m1[g], sel[g]); }
-            }
-            // a quarter of the next stage's expansion
-            if (cBegin + (st + 1) * kMStage + srow < cEnd) {
-                const uint32_t d = i == 0 ? pre.x : i == 1 ? pre.y : i == 2 ? pre.z : pre.w;
-                stage_write_dword(frag[(st + 1) & 1], srow, 4 * shalf + i, d);
-            }
-            if (i == 3) { pre = pre2; __syncthreads(); }
-        };
-
-        v16i X[G], Y[G];
-        if (nTiles > 0) {
-            step(X, Y, 0, false);
-            int tt = 1;
-            for (; tt + 1 < nTiles; tt += 2) { step(Y, X, tt, true); step(X, Y, tt + 1, true); }
-            const int left = cEnd - (cBegin + (nTiles - 1) * 32);     // rows of the last tile
-            if (tt < nTiles) {
-                step(Y, X, tt, true);
+                for (int s = 0; s < 8; ++s) {
+                    const v4i A = fp[s * 64];
 #pragma unroll
-                for (int g = 0; g < G; ++g) { if (left >= 32 && SECOND) select16(m1[g], m2[g], Y[g]); else select16_ragged(m1[g], m2[g], Y[g], h, left); }
-            } else {
+                    for (int g = 0; g < G; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[g][s], s == 0 ? C : acc[g], 0, 0, 0);
+                }
 #pragma unroll
-                for (int g = 0; g < G; ++g) { if (left >= 32 && SECOND) select16(m1[g], m2[g], X[g]); else select16_ragged(m1[g], m2[g], X[g], h, left); }
+                for (int g = 0; g < G; ++g) select16_ragged(m1[g], m2[g], acc[g], h, left);
             }
         }
         // back to the (dist << 23 | trainIdx) keys: the row field now counts from the end of the last tile
@@ -222,11 +225,13 @@ __global__ __launch_bounds__(256, MINW) void k_hamming_knn2_mfma(MatchArgs a)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             uint32_t k[2];
+            // group G - 1 was selected once more than the others (the sentinel chain before the first tile): one more -32 ...
+            // which only ever touched sentinels, so its real keys carry the same offsets as everyone's
             const int m[2] = {m1[g], m2[g]};
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int K = m[i] + 8192 * na[g];
-                k[i] = m[i] >= 0x30000000 ? kKeyInit : ((uint32_t)(K >> 13) << 23) | (uint32_t)(tEnd + (K & 8191) - kMFBase);
+                const int K = m[i] - kMBias + 8192 * na[g];
+                k[i] = m[i] >= 0x70000000 ? kKeyInit : ((uint32_t)(K >> 13) << 23) | (uint32_t)(tEnd + (K & 8191) - kMFBase);
             }
             // the other half-wave holds the same query's keys over the other 16 rows of every tile
             const uint32_t o1 = __shfl_xor(k[0], 32), o2 = __shfl_xor(k[1], 32);
@@ -238,13 +243,14 @@ __global__ __launch_bounds__(256, MINW) void k_hamming_knn2_mfma(MatchArgs a)
     }
 }
 
-// query groups of 32 per wave (tuning knob: SSVIO_MFMA_G).  2 groups = 256 query rows per workgroup: two accumulator sets fit 226
-// registers without spills, two workgroups per CU
+// query groups of 32 per wave (tuning knob: SSVIO_MFMA_G): 2 or 3 -- the skewed chains need at least two accumulator sets, and four
+// groups of fragments do not fit the 256 registers that two workgroups per CU leave a wave
 int knn2_mfma_groups(int maxQ)
 {
     static const int forced = [] { const char* e = getenv("SSVIO_MFMA_G"); return e ? atoi(e) : 0; }();
-    if (forced >= 1 && forced <= 4) return forced;
-    return maxQ > 128 ? 2 : 1;
+    if (forced == 2 || forced == 3) return forced;
+    (void)maxQ;
+    return 2;
 }
 
 int knn2_mfma_query_blocks(int maxQ)
@@ -256,10 +262,8 @@ int knn2_mfma_query_blocks(int maxQ)
 template <bool SECOND>
 static void launch_mfma_g(const MatchArgs& a, int G, dim3 grid, hipStream_t s)
 {
-    if (G == 4) hipLaunchKernelGGL((k_hamming_knn2_mfma<4, 1, SECOND>), grid, dim3(256), 0, s, a);
-    else if (G == 3) hipLaunchKernelGGL((k_hamming_knn2_mfma<3, 2, SECOND>), grid, dim3(256), 0, s, a);
-    else if (G == 2) hipLaunchKernelGGL((k_hamming_knn2_mfma<2, 2, SECOND>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_hamming_knn2_mfma<1, 2, SECOND>), grid, dim3(256), 0, s, a);
+    if (G == 3) hipLaunchKernelGGL((k_hamming_knn2_mfma<3, 2, SECOND>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_hamming_knn2_mfma<2, 2, SECOND>), grid, dim3(256), 0, s, a);
 }
 
 // needSecond = false: only the nearest neighbour is searched (the second key of every partial entry is kKeyInit)

@@ -28,7 +28,7 @@ if len(sys.argv) > 1:
                   pe / (us["k_hamming_knn2"] * 1e-6)), flush=True)
             fm.close()
 else:
-    for env in ({}, {"SSVIO_MFMA_G": "3"}, {"SSVIO_MFMA_G": "4"}, {"SSVIO_MFMA_BLOCKS": "512"}, {"SSVIO_MFMA_BLOCKS": "2048"}):
+    for env in ({}, {"SSVIO_MFMA_G": "3"}, {"SSVIO_MFMA_BLOCKS": "2048"}):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, __file__, " ".join("%s=%s" % (k.replace("SSVIO_MFMA_", ""), v) for k, v in env.items()) or "default"], env=e, capture_output=True, text=True, timeout=200)
         print(r.stdout.strip() or r.stderr[-600:], flush=True)
