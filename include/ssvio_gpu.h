@@ -229,6 +229,21 @@ typedef struct ssvio_pair_summary { int32_t pair; int32_t n_matches; int64_t sum
 #define SSVIO_PAIR_ID_SEQUENTIAL 0
 #define SSVIO_PAIR_ID_TRIANGULAR 1
 int  ssvio_match_batch_summary_dev(ssvio_matcher* m, int id_mode, int id_base, void* d_records);
+/* The rank's share of the loop-candidate walk (BASELINE config 5; what a C++ `Loop` -- empty in the reference, include/Loop.h:1-4,
+ * src/Loop.cpp:1 -- would call): all unordered pairs (i, j), j < i, of nsets key frames, every pair-block matched as
+ * MatchByBruteForce(desc_i, desc_j) does (src/FeatureMatching.cpp:20-55; `mode` may select one of the other filters) and reduced on the
+ * device to one ssvio_pair_summary with the pair's triangular id i*(i-1)/2 + j.  The triangular block matrix is cut into super-blocks
+ * of sb x sb key frames which are dealt to `world` ranks, largest first onto the least loaded rank (ties: lowest rank) -- a pure
+ * function of (nsets, sb, world), so every rank computes the same deal; ssvio_loop_candidates_plan returns this rank's number of
+ * records, the largest number any rank gets (the fixed record size of an all_gather) and this rank's number of super-blocks.
+ * ssvio_loop_candidates_dev walks this rank's super-blocks -- pair list built on the device, one batched matcher pass and one
+ * k_pair_summary launch per super-block, matcher scratch bounded by sb*sb pair-blocks -- and writes its records, in walk order, to
+ * d_records[0 .. *n_records) (device memory, records_cap entries).  Everything is enqueued on the handle's stream; nothing waits and
+ * nothing returns to the host.  Descriptor layout as ssvio_match_batch_dev.  The collective (one all_gather of the records: RCCL
+ * over xGMI) stays with the caller -- ssvio_amd/dist.py:loop_candidates is that caller. */
+int  ssvio_loop_candidates_plan(int nsets, int sb, int rank, int world, int64_t* n_mine, int64_t* n_max, int* n_tiles);
+int  ssvio_loop_candidates_dev(ssvio_matcher* m, const void* d_desc, int set_stride_rows, int max_rows, const int32_t* d_counts,
+                               int nsets, int sb, int rank, int world, int mode, void* d_records, int64_t records_cap, int64_t* n_records);
 /* The same batched matcher for callers that cannot allocate.  No counterpart in the reference: it exists for callers under HIP
  * graph capture, tight serving loops and harnesses that forbid hipMalloc.  The call allocates nothing (no hipMalloc / hipFree /
  * pinned memory / events / copy commands): pair list, inputs and outputs are the caller's DEVICE memory -- d_pairs[npairs][2] int32,

@@ -89,6 +89,8 @@ SYMBOLS = {
     "ssvio_match_knn2_raw": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ssvio_match_batch_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "ssvio_match_batch_summary_dev": (_i, [_vp, _i, _i, _vp]),
+    "ssvio_loop_candidates_plan": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "ssvio_loop_candidates_dev": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, C.c_int64, _vp]),
     "ssvio_match_batch_dev_noalloc": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "ssvio_matcher_sync": (_i, [_vp]),
     "ssvio_match_batch_fetch": (_i, [_vp, _i, _i, _vp, _vp]),

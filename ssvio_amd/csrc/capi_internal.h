@@ -117,5 +117,6 @@ int match_plan(int maxQ, int maxT, int npairs, int mode, int kernel, size_t limi
 int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
                  const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts, const int* d_pairs, int npairs, int maxQ, int maxT, int mode,
                  uint2* partial, uint2* partialRev, ssvio_dmatch* out, int* nout, int32_t* raw, bool profile);
+int match_batch_on_device_pairs(ssvio_matcher* m, const uint8_t* d_desc, int strideRows, const int* d_counts, int npairs, int maxRows, int mode);   // capi_match.hip
 // mapped host landing area for {count, pad to 16 B, rows} of at least rowBytes (capi_match.hip)
 int ensure_result(ssvio_matcher* m, size_t rowBytes);

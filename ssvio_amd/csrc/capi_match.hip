@@ -47,12 +47,15 @@ static void pick_chunks(int maxQ, int maxT, int npairs, bool mfma, int& nChunks,
 // the pair list of the batched entry points, on the device (an unchanged list is not uploaded again)
 int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs)
 {
-    if (m->h_pairs.size() == (size_t)npairs * 2 && memcmp(m->h_pairs.data(), pairs, (size_t)npairs * 2 * sizeof(int32_t)) == 0) return SSVIO_OK;
+    if (m->d_pairs && m->h_pairs.size() == (size_t)npairs * 2 && memcmp(m->h_pairs.data(), pairs, (size_t)npairs * 2 * sizeof(int32_t)) == 0) return SSVIO_OK;
+    // the cache describes the device copy only after everything below has succeeded: a failed allocation or copy must not leave an
+    // earlier list looking current (the next call with that list would launch on a stale or null d_pairs)
+    m->h_pairs.clear();
     int rc = grow(m->d_pairs, m->pairsCap, (size_t)npairs * 2, m->stream); if (rc) return rc;
     SSVIO_HIP(hipStreamSynchronize(m->stream));    // earlier launches may still read the old list
-    m->h_pairs.assign(pairs, pairs + (size_t)npairs * 2);
-    SSVIO_HIP(hipMemcpyAsync(m->d_pairs, m->h_pairs.data(), (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    SSVIO_HIP(hipMemcpyAsync(m->d_pairs, pairs, (size_t)npairs * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
     SSVIO_HIP(hipStreamSynchronize(m->stream));
+    m->h_pairs.assign(pairs, pairs + (size_t)npairs * 2);
     return SSVIO_OK;
 }
 
@@ -162,6 +165,15 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
                       m->d_partial, m->d_partialRev, outTo ? outTo : m->d_out, noutTo ? noutTo : m->d_nout, rawTo ? rawTo : m->d_raw, true);
     if (rc) return rc;
     m->lastPairs = npairs; m->lastMaxRows = p.maxRows; m->lastHadPairs = false;
+    return SSVIO_OK;
+}
+
+// the batched matcher over a pair list that is already in m->d_pairs (capi_loop.hip builds it on the device)
+int match_batch_on_device_pairs(ssvio_matcher* m, const uint8_t* d_desc, int strideRows, const int* d_counts, int npairs, int maxRows, int mode)
+{
+    const int rc = match_run(m, d_desc, strideRows, d_counts, d_desc, strideRows, d_counts, m->d_pairs, npairs, maxRows, maxRows, mode);
+    if (rc) return rc;
+    m->lastHadPairs = true;
     return SSVIO_OK;
 }
 

@@ -101,6 +101,12 @@ class DeviceBlocks:
         src_n = torch.as_tensor(_DevBytes(dn, n * 4), device=self.device).view(torch.int32)
         dst_m.view(-1).copy_(src_m); dst_n.copy_(src_n)
 
+    def loop_walk(self, nsets, sb, rank, world, mode, local):
+        """this rank's super-blocks in one native call (ssvio_loop_candidates_dev): records into local[:load[rank]]"""
+        assert local.is_cuda and local.dtype == torch.int32 and local.is_contiguous() and local.shape[1] == 4
+        return self.fm.loop_candidates_dev(self.d_desc, self.set_stride_rows, self.max_rows, self.d_counts, nsets, sb, rank, world, mode,
+                                           local, local.shape[0])
+
     def publish(self):
         """results produced on the blocks' stream become visible to the caller's current torch stream"""
         torch.cuda.current_stream(self.device).wait_stream(self.st)
@@ -126,6 +132,13 @@ def gather_fixed(local, world, group=None):
     else:
         dist.all_gather(list(out.unbind(0)), local, group=group)
     return out
+
+def _hand_over(blocks, *tensors):
+    """results were allocated while the blocks' stream was current: tell the caching allocator that the caller's stream reads
+    them too, so their memory is not handed out again (to work on the blocks' stream) while that stream still does"""
+    for t in tensors:
+        if t.is_cuda:
+            t.record_stream(torch.cuda.current_stream(t.device))
 
 # ---------------------------------------------------------------- config 4
 def window_matches(blocks, pairs, rank, world, mode=MODE_CROSSCHECK, group=None, work=None):
@@ -153,6 +166,7 @@ def window_matches(blocks, pairs, rank, world, mode=MODE_CROSSCHECK, group=None,
         p = torch.arange(npairs, device=blocks.device)
         res = gl[p % world, p // world], gc[p % world, p // world]
     blocks.publish()
+    _hand_over(blocks, *res)
     return res
 
 def lists_to_numpy(lists, counts):
@@ -177,12 +191,17 @@ def loop_candidates(blocks, nsets, rank, world, sb=32, mode=MODE_BRUTEFORCE, gro
             work[key] = torch.empty((per, 4), dtype=torch.int32, device=blocks.device)
         local = work[key]
         local[load[rank]:, 0] = -1                                               # padding records
-        o = 0
-        for bi, bj in plan[rank]:
-            pairs = super_block_pairs(bi, bj, sb, nsets)
-            blocks.match(pairs, mode)
-            blocks.summaries_into(local[o:o + len(pairs)], PAIR_ID_TRIANGULAR)
-            o += len(pairs)
+        if hasattr(blocks, "loop_walk"):
+            # the product path: the whole walk of this rank is one C-ABI call (same deal, computed natively; checked against this
+            # module's deal_super_blocks in tests/test_cabi_and_host.py)
+            o = blocks.loop_walk(nsets, sb, rank, world, mode, local)
+        else:
+            o = 0
+            for bi, bj in plan[rank]:
+                pairs = super_block_pairs(bi, bj, sb, nsets)
+                blocks.match(pairs, mode)
+                blocks.summaries_into(local[o:o + len(pairs)], PAIR_ID_TRIANGULAR)
+                o += len(pairs)
         assert o == load[rank]
         g = gather_fixed(local, world, group).reshape(world * per, 4)
         ids = g[:, 0].long()
@@ -190,6 +209,7 @@ def loop_candidates(blocks, nsets, rank, world, sb=32, mode=MODE_BRUTEFORCE, gro
         out = torch.zeros((npairs, 4), dtype=torch.int32, device=blocks.device)
         out[ids[keep]] = g[keep]
     blocks.publish()
+    _hand_over(blocks, out)
     return out
 
 def records_to_numpy(rec):

@@ -250,6 +250,20 @@ class FeatureMatching:
         """16-byte {pair, n_matches, sum_dist} records of the last batched call, reduced on the device into d_records"""
         L.check(L.lib().ssvio_match_batch_summary_dev(self._h, id_mode, id_base, L.ptr(d_records)))
 
+    @staticmethod
+    def loop_candidates_plan(nsets, sb, rank, world):
+        """-> (records of this rank, largest number of records on any rank, super-blocks of this rank); host arithmetic only"""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        L.check(L.lib().ssvio_loop_candidates_plan(nsets, sb, rank, world, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def loop_candidates_dev(self, d_desc, set_stride_rows, max_rows, d_counts, nsets, sb, rank, world, mode, d_records, records_cap):
+        """ssvio_loop_candidates_dev: this rank's super-block walk, records into d_records (device); -> number of records"""
+        n = C.c_int64(0)
+        L.check(L.lib().ssvio_loop_candidates_dev(self._h, L.ptr(d_desc), set_stride_rows, max_rows, L.ptr(d_counts), nsets, sb, rank, world,
+                                                  mode, L.ptr(d_records), records_cap, C.byref(n)))
+        return n.value
+
     def match_batch_dev_noalloc(self, d_desc, set_stride_rows, max_rows, d_counts, d_pairs, npairs, mode, d_matches, d_nmatches):
         """ssvio_match_batch_dev_noalloc: every pointer is the caller's device memory (torch tensors or raw addresses)"""
         L.check(L.lib().ssvio_match_batch_dev_noalloc(self._h, L.ptr(d_desc), set_stride_rows, max_rows, L.ptr(d_counts), L.ptr(d_pairs),

@@ -106,3 +106,16 @@ def test_header_is_plain_c99_and_links_from_c(tmp_path):
                            "-o", str(exe), "-L", lib, "-lssvio_gpu", "-Wl,-rpath," + lib])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr           # without a GPU: SSVIO_ERR_NOGPU and a message, never a crash or a fallback
+
+
+def test_native_super_block_plan_equals_the_python_deal():
+    """ssvio_loop_candidates_plan (host arithmetic of the C ABI, no GPU) against ssvio_amd.dist.deal_super_blocks: every rank's
+    number of records, the largest one and the number of super-blocks"""
+    import ssvio_amd
+    from ssvio_amd import dist as D, _lib as L
+    for nsets, sb, world in [(12, 4, 1), (12, 5, 2), (64, 8, 8), (4096, 32, 8), (100, 7, 3), (1, 4, 2), (0, 4, 1), (33, 32, 4), (4096, 64, 8)]:
+        plan, load = D.deal_super_blocks(nsets, sb, world)
+        for r in range(world):
+            assert ssvio_amd.FeatureMatching.loop_candidates_plan(nsets, sb, r, world) == (load[r], max(load), len(plan[r]))
+    with pytest.raises(ssvio_amd.SsvioError):
+        ssvio_amd.FeatureMatching.loop_candidates_plan(10, 0, 0, 1)

@@ -97,3 +97,50 @@ def test_config5_full_size_blocks_through_the_driver(mods):
     for k, w in zip((0, 5), want):
         assert n[k] == len(w) and np.array_equal(lists[k, :n[k]].view(np.uint8), w.view(np.uint8))
     fm.close()
+
+
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+def test_native_walk_equals_the_python_walk(mods, kernel):
+    """ssvio_loop_candidates_dev (the rank's super-blocks in one C-ABI call, pair lists built on the device) against the per-tile
+    Python walk over ssvio_match_batch_dev + ssvio_match_batch_summary_dev: same records, for 1 and 3 ranks' shares and two modes"""
+    torch, S, synth, D, L, O = mods
+    rng = np.random.default_rng(17)
+    nsets, stride = 11, 704
+    counts = [int(c) for c in rng.integers(300, 701, nsets)]
+    counts[2] = 0; counts[7] = 700
+    base = synth.descriptor_sets(56, 8, 700)[1]
+    buf = np.zeros((nsets, stride, 32), np.uint8)
+    for s, c in enumerate(counts):
+        buf[s, :c] = base[rng.permutation(700)[:c]] ^ np.packbits(rng.random((c, 256)) < 0.05, axis=1, bitorder="little")
+    fm = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
+    fm.set_kernel(kernel)
+    blocks = D.DeviceBlocks(fm, torch.from_numpy(buf).cuda(), stride, 700, torch.tensor(counts, dtype=torch.int32).cuda(), "cuda:0")
+
+    class PythonWalk:                                             # the same blocks without the native walk
+        def __getattr__(self, name):
+            if name == "loop_walk":
+                raise AttributeError(name)
+            return getattr(blocks, name)
+    npairs = nsets * (nsets - 1) // 2
+    for mode in (L.MODE_BRUTEFORCE, L.MODE_KNN2_RATIO):
+        for world, sb in ((1, 4), (3, 3)):
+            nat = np.zeros(npairs, L.REC_DTYPE); py = np.zeros(npairs, L.REC_DTYPE)
+            for rank in range(world):                              # a rank's own records are everything but the other ranks' zeros
+                a = D.records_to_numpy(_one_rank(D, blocks, nsets, rank, world, sb, mode))
+                b = D.records_to_numpy(_one_rank(D, PythonWalk(), nsets, rank, world, sb, mode))
+                assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (mode, world, rank)
+                nat["pair"] += a["pair"]; nat["n_matches"] += a["n_matches"]; nat["sum_dist"] += a["sum_dist"]
+            assert nat["pair"].tolist() == list(range(npairs))     # every pair exactly once over the ranks
+    fm.close()
+
+
+def _one_rank(D, blocks, nsets, rank, world, sb, mode):
+    """loop_candidates for one rank's share without a process group: what the rank contributes before the all_gather"""
+    import unittest.mock as mock
+    import torch
+    def alone(local, w, group=None):                               # the other ranks contribute padding records only
+        out = torch.full((w,) + tuple(local.shape), -1, dtype=local.dtype, device=local.device)
+        out[rank] = local
+        return out
+    with mock.patch.object(D, "gather_fixed", alone):
+        return D.loop_candidates(blocks, nsets, rank, world, sb=sb, mode=mode)

@@ -243,6 +243,35 @@ def test_failed_allocation_is_reported_and_the_handle_recovers(mods):
     fm.close()
 
 
+def test_failed_pair_list_upload_does_not_leave_a_stale_list_looking_current(mods):
+    """list X ok, then a larger list Y whose device copy cannot be allocated, then X again -- the cached host copy of X
+    must not make the call skip the upload (the device list is gone); the batch must equal the oracle"""
+    import torch
+    from ssvio_amd import _lib as L
+    S, synth, O = mods
+    fm = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
+    q, t = synth.descriptor_sets(43, 600, 600)
+    buf = np.stack([q[:300], q[300:], t[:300], t[300:]])
+    d = torch.from_numpy(buf).cuda(); c = torch.tensor([300, 299, 300, 17], dtype=torch.int32).cuda()
+    X = np.array([[0, 2], [1, 3], [3, 0]], np.int32)
+    Y = np.tile(np.array([[0, 1], [2, 3]], np.int32), (4000, 1))      # 8000 pairs: d_pairs has to grow (and so do the result buffers)
+
+    def check():
+        fm.match_batch_dev(d, 300, 300, c, X, L.MODE_BRUTEFORCE); fm.sync()
+        got, n = fm.fetch_batch()
+        cnt = [300, 299, 300, 17]
+        for k, (a, b) in enumerate(X):
+            w = O.match_bruteforce(buf[a, :cnt[a]], buf[b, :cnt[b]])
+            assert n[k] == len(w) and np.array_equal(got[k, :n[k]].view(np.uint8), w.view(np.uint8))
+    check()
+    L.lib().ssvio_test_fail_next_allocs(1)                            # the first growing allocation of the next call is d_pairs
+    with pytest.raises(S.SsvioError):
+        fm.match_batch_dev(d, 300, 300, c, Y, L.MODE_BRUTEFORCE)
+    L.lib().ssvio_test_fail_next_allocs(0)
+    check()
+    fm.close()
+
+
 def test_match_by_project_empty_window_keeps_index_minus_one(mods):
     """a reference point that projects inside the image with no train keypoint in its window keeps best_id = -1 and
     min_dist = 256 (src/FeatureMatching.cpp:160-170); with Threshold > 256 the reference still emits it (:177)"""
