@@ -36,15 +36,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # instruction per SIMD, v_bcnt_u32_b32 / v_lshl_or_b32 / v_med3_u32 / v_min_u32 4.13
 MATCH_CYCLES_PER_PAIR = 8 * 2.46 + 11 * 4.13
 VALU_PEAK_PAIRS = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR      # 1024 SIMDs x 2.4 GHz x 64 lanes = 2.42e12 pairs/s
+# k_hamming_knn2_mfma: 8 x v_mfma_i32_32x32x32_i8 (32 cycles each per SIMD, MI355X_MICROARCH.md matrix table) per 32 x 32 descriptor pairs
+MFMA_PEAK_PAIRS = 256 * 4 * 2.4e9 * 1024 / (8 * 32)                 # 9.83e12 pairs/s at the nominal clock
 
 
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r2")
-PMC_FILE = os.path.join(PROFILE_DIR, "r2_final_pmc_hbm.json")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r3")
+PMC_FILE = os.path.join(PROFILE_DIR, "r3_final_pmc_hbm.json")
 
 
 def kernel_source_hash():
     """sha256 over the kernel sources: the committed rocprof / PMC figures are only carried into the line while this matches
-    the hash stored beside them (profiles/r2/r2_final_source_hash.txt, written by tools/gpu_profile.sh) -- a kernel change
+    the hash stored beside them (profiles/r3/r3_final_source_hash.txt, written by tools/gpu_profile.sh) -- a kernel change
     without a fresh profile turns them into nulls instead of replaying stale numbers"""
     import glob
     import hashlib
@@ -56,7 +58,7 @@ def kernel_source_hash():
 
 def profiles_current():
     try:
-        return open(os.path.join(PROFILE_DIR, "r2_final_source_hash.txt")).read().strip() == kernel_source_hash()
+        return open(os.path.join(PROFILE_DIR, "r3_final_source_hash.txt")).read().strip() == kernel_source_hash()
     except OSError:
         return False
 
@@ -75,15 +77,18 @@ def pmc_traffic(kernel):
     return None
 
 
-STATS_FILE = os.path.join(PROFILE_DIR, "r2_final_kernel_stats.csv")
+STATS_FILE = os.path.join(PROFILE_DIR, "r3_final_kernel_stats.csv")
 
 
-def rocprof_avg_us(kernel):
+STATS_1080P_FILE = os.path.join(PROFILE_DIR, "r3_1080p_kernel_stats.csv")
+
+
+def rocprof_avg_us(kernel, stats_file=None):
     """average duration of `kernel` in the committed `rocprofv3 --kernel-trace --stats` summary of this same command
     (tools/gpu_profile.sh), for comparison with the live hipEvent figures; None when the file is absent"""
     import csv
     try:
-        for r in csv.DictReader(open(STATS_FILE)):
+        for r in csv.DictReader(open(stats_file or STATS_FILE)):
             if r["Name"].replace("void ", "").startswith("ssvio::" + kernel + "<") or r["Name"].replace("void ", "").startswith("ssvio::" + kernel + "("):
                 return round(float(r["AverageNs"]) / 1e3, 2)
     except (OSError, ValueError, KeyError):
@@ -91,22 +96,28 @@ def rocprof_avg_us(kernel):
     return None
 
 
-SQ_FILE = os.path.join(PROFILE_DIR, "r2_final_pmc_sq.txt")
+SQ_FILE = os.path.join(PROFILE_DIR, "r3_final_pmc_sq.txt")
+MIX_FILE = os.path.join(PROFILE_DIR, "valu_mix.json")
 
 
 def valu_busy(kernel, kernel_us):
-    """share of the chip's VALU issue capacity the kernel uses: SQ_ACTIVE_INST_VALU (cycles a SIMD spends issuing VALU, summed)
-    x 4 / (1024 SIMDs x kernel cycles at 2.4 GHz), counter from the committed rocprofv3 --pmc pass (tools/gpu_pmc.sh); None if absent"""
+    """share of the chip's VALU issue capacity the kernel uses: SQ_INSTS_VALU (wave-instructions, summed over the chip; committed
+    rocprofv3 --pmc pass, tools/gpu_pmc.sh) x the kernel's average issue cycles per instruction / (1024 SIMDs x kernel cycles at
+    2.4 GHz).  The issue cycles come from the two classes measured on this chip (profiles/r2/ubench_valu_table.txt: ~2.4 cycles
+    for and / or / xor / add / sub / right shifts / mov, ~4.2 for the rest, ~5 for v_cmp) weighted by the kernel's static
+    instruction mix (tools/valu_mix.py -> profiles/r3/valu_mix.json).  -> (busy, average issue cycles) or (None, None)"""
     import re
     try:
+        mix = json.load(open(MIX_FILE))
+        cyc = next(v["avg_issue_cycles"] for k, v in sorted(mix.items(), reverse=True) if k == kernel or k.startswith(kernel + "<"))
         for line in open(SQ_FILE):
             if line.startswith(kernel + "<") or line.startswith(kernel + " "):
-                m = re.search(r"SQ_ACTIVE_INST_VALU=([0-9.e+]+)", line)
+                m = re.search(r"SQ_INSTS_VALU=([0-9.e+]+)", line)
                 if m and kernel_us > 0:
-                    return round(float(m.group(1)) * 4 / (1024 * kernel_us * 2400.0), 3)
-    except OSError:
+                    return round(float(m.group(1)) * cyc / (1024 * kernel_us * 2400.0), 3), cyc
+    except (OSError, ValueError, StopIteration, KeyError):
         pass
-    return None
+    return None, None
 
 
 def level_pixels(ex, w, h):
@@ -140,54 +151,76 @@ def algorithmic_bytes(kernel, B, px, nkp_total, pairs_rows):
     return 0
 
 
-def cpu_baseline(frames, nfeatures, match_mode="bf", budget_s=12.0):
-    """oracle extract + BF match vs previous frame, 1 thread, bounded sample of the same frames"""
+def _pcts(ms):
+    ms = sorted(ms)
+    return {"median_ms_per_frame": round(ms[len(ms) // 2], 3), "p95_ms_per_frame": round(ms[min(len(ms) - 1, int(0.95 * len(ms)))], 3)} if ms else {}
+
+
+_MATCHERS = {"bf": "match_bruteforce", "ratio": "match_knn2_ratio", "crosscheck": "match_crosscheck", "dbow": "match_knn2_ratio"}   # dbow: the CPU leg times the all-rows 2-NN loop (no 1.1 M-node tree on the host side)
+
+
+def cpu_baseline(frames, nfeatures, match_mode="bf", budget_s=10.0):
+    """oracle extract + match vs previous frame, 1 thread (the reference's application-level behaviour), bounded sample of the same
+    frames; median and p95 per frame"""
     from oracle import oracle as O
     ex = O.Extractor(nfeatures, 1.2, 8, 20, 7)
+    fn = getattr(O, _MATCHERS[match_mode])
     prev = None
     n = 0
+    per = []
     t0 = time.perf_counter()
     while True:
-        f = frames[n % len(frames)]
-        k, d = ex.extract(f)
+        ta = time.perf_counter()
+        k, d = ex.extract(frames[n % len(frames)])
         if prev is not None:
-            {"bf": O.match_bruteforce, "ratio": O.match_knn2_ratio, "crosscheck": O.match_crosscheck,
-             "dbow": O.match_knn2_ratio}[match_mode](d, prev)      # dbow: the CPU leg times the all-rows 2-NN loop (no 1.1 M-node tree on the host side)
+            fn(d, prev) if match_mode in ("bf", "crosscheck") else fn(d, prev, 50, 0.6)
+            per.append((time.perf_counter() - ta) * 1e3)
         prev = d
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= 8 * len(frames):
             break
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of %dx%d (extract %d features + %s match vs previous), oracle C restatement, 1 thread, %.1f s"
-                      % (n, frames.shape[2], frames.shape[1], nfeatures, match_mode, dt)}
+    out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of %dx%d (extract %d features + %s match vs previous), oracle C restatement, 1 thread, %.1f s"
+                     % (n, frames.shape[2], frames.shape[1], nfeatures, match_mode, dt)}
+    out.update(_pcts(per))
+    return out
 
 
-def cpu_baseline_all_cores(frames, nfeatures, match_mode="bf", budget_s=8.0):
+def cpu_baseline_all_cores(frames, nfeatures, match_mode="bf", budget_s=6.0):
     """BASELINE.md's second CPU point: the same oracle work spread over the host cores this job may use (one oracle
     extractor per thread; ctypes releases the GIL inside the C calls).  Reported beside cpu_baseline, never the target."""
     import concurrent.futures as cf
     from oracle import oracle as O
     cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1, 16))
-    fn = {"bf": O.match_bruteforce, "ratio": O.match_knn2_ratio, "crosscheck": O.match_crosscheck, "dbow": O.match_knn2_ratio}[match_mode]
+    fn = getattr(O, _MATCHERS[match_mode])
     deadline = time.perf_counter() + budget_s
 
     def worker(tid):
         ex = O.Extractor(nfeatures, 1.2, 8, 20, 7)
-        prev = None; n = 0
+        prev = None; per = []
         while time.perf_counter() < deadline:
-            k, d = ex.extract(frames[(tid + n * cores) % len(frames)])
+            ta = time.perf_counter()
+            k, d = ex.extract(frames[(tid + len(per) * cores) % len(frames)])
             if prev is not None:
-                fn(d, prev)
-            prev = d; n += 1
-        return n
+                fn(d, prev) if match_mode in ("bf", "crosscheck") else fn(d, prev, 50, 0.6)
+            prev = d; per.append((time.perf_counter() - ta) * 1e3)
+        return per
 
     t0 = time.perf_counter()
     with cf.ThreadPoolExecutor(cores) as pool:
-        done = sum(pool.map(worker, range(cores)))
+        pers = list(pool.map(worker, range(cores)))
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames in %.1f s, one oracle extractor per thread" % (done, dt)}
+    done = sum(len(p) for p in pers)
+    out = {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "%d frames in %.1f s, one oracle extractor per thread" % (done, dt)}
+    out.update(_pcts([m for p in pers for m in p]))
+    return out
+
+
+def cpu_points(frames, nfeatures, match_mode, b1, bn):
+    """the two CPU points BASELINE.md plans per config"""
+    return {"one_thread": cpu_baseline(frames, nfeatures, match_mode, b1), "all_cores": cpu_baseline_all_cores(frames, nfeatures, match_mode, bn)}
 
 
 def batched_matching(rank, world, dev, dist, iters=10):
@@ -235,11 +268,18 @@ def batched_matching(rank, world, dev, dist, iters=10):
     dt = timed(cfg4)
     trace('cfg4 done')
     total = int(res["counts"].sum().item())
+    fm.set_kernel("mfma")
+    dtm = timed(cfg4)
+    totalm = int(res["counts"].sum().item())
+    fm.set_kernel("valu")
     per = (nkf + world - 1) // world
     out.append({"config": "configs[3]: 1 query x %d keyframes x %d descriptors, cross-check, pair-blocks over %d rank(s) "
                           "(ssvio_amd.dist.window_matches), all_gather of DMatch lists (%d KB per rank)" % (nkf, rows, world, (per * rows * 16 + per * 4) // 1024),
-                "scaling": "strong", "ms": round(dt * 1e3, 4), "descriptor_pairs_per_s": 2.0 * nkf * rows * rows / dt,
-                "query_matches_per_s": total / dt, "matches": total})
+                "scaling": "strong", "kernel": "k_hamming_knn2 (VALU xor + popcount, the library's default)",
+                "ms": round(dt * 1e3, 4), "descriptor_pairs_per_s": 2.0 * nkf * rows * rows / dt,
+                "query_matches_per_s": total / dt, "matches": total,
+                "mfma_kernel": {"kernel": "k_hamming_knn2_mfma (SSVIO_KERNEL_MFMA: exact int8 contraction, same results)", "ms": round(dtm * 1e3, 4),
+                                "descriptor_pairs_per_s": 2.0 * nkf * rows * rows / dtm, "matches": totalm, "speedup": round(dt / dtm, 3)}})
 
     # ---- config 5 (timed subset, stated): loop-candidate all-pairs over 64 of the 4096 keyframes, 8000 descriptors each:
     # 2016 pair-blocks of 8000 x 8000 walked in super-blocks of 8 x 8 keyframes (36 tiles dealt to the ranks), per-pair summary
@@ -257,7 +297,12 @@ def batched_matching(rank, world, dev, dist, iters=10):
     iters = 3
     dt5 = timed(cfg5)
     trace('cfg5 done')
+    recv = D.records_to_numpy(res["rec"])
+    fm.set_kernel("mfma")
+    dt5m = timed(cfg5)
+    fm.set_kernel("valu")
     rec = D.records_to_numpy(res["rec"])
+    assert np.array_equal(rec.view(np.uint8), recv.view(np.uint8)), "the two matcher kernels disagree"
     npairs5 = nset5 * (nset5 - 1) // 2
     assert rec["pair"].tolist() == list(range(npairs5))
     total5 = int(rec["n_matches"].sum())
@@ -268,9 +313,16 @@ def batched_matching(rank, world, dev, dist, iters=10):
                 "scaling": "strong", "ms": round(dt5 * 1e3, 4), "pair_blocks_per_rank": load,
                 "descriptor_pairs_per_s": float(npairs5) * rows5 * rows5 / dt5, "query_matches_per_s": total5 / dt5, "matches": total5,
                 "sum_dist": int(rec["sum_dist"].sum()),
+                "kernel": "k_hamming_knn2 (VALU xor + popcount, the library's default)",
                 "valu_frac": round(float(npairs5) * rows5 * rows5 / dt5 / (world * VALU_PEAK_PAIRS), 4),
+                "mfma_kernel": {"kernel": "k_hamming_knn2_mfma (SSVIO_KERNEL_MFMA), identical records", "ms": round(dt5m * 1e3, 4),
+                                "descriptor_pairs_per_s": float(npairs5) * rows5 * rows5 / dt5m, "speedup": round(dt5 / dt5m, 3),
+                                "mfma_frac": round(float(npairs5) * rows5 * rows5 / dt5m / (world * MFMA_PEAK_PAIRS), 4),
+                                "mfma_frac_note": "of 1024 SIMDs x one v_mfma_i32_32x32x32_i8 (1024 descriptor-pair bits x 32) per 32 cycles at 2.4 GHz = 9.83e12 pairs/s; "
+                                                  "the chip holds ~2.05 GHz under this kernel (GRBM_GUI_ACTIVE, profiles/r3/mfma_*)"},
+                "full_config_measured_1gpu": "profiles/r3/config5_full_1gpu.json: all 8 386 560 pair-blocks on ONE MI355X, 249.1 s (VALU kernel) / 74.3 s (MFMA kernel)",
                 "full_config_extrapolated_s": round(dt5 * (4096 * 4095 / 2) / npairs5 * world / 8, 1),
-                "full_config_note": "8 386 560 pair-blocks on 8 GPUs at this per-GPU rate"})
+                "full_config_note": "8 386 560 pair-blocks on 8 GPUs at this per-GPU rate (VALU kernel)"})
     fm.close()
     return out
 
@@ -311,7 +363,7 @@ class Pipeline:
             h.close()
 
 
-def extra_configs(dev, frames_vga):
+def extra_configs(dev, frames_vga, with_cpu=True):
     """The single-GPU BASELINE configs that are not the headline, measured in this same process (N = 1 only): every one is its own
     timed region with a device synchronise on both sides."""
     from ssvio_amd import synth, _lib as L
@@ -349,6 +401,7 @@ def extra_configs(dev, frames_vga):
     out.append({"config": "configs[0] on the GPU: one 640x480 frame per step, 500 features, extract + MatchByBruteForce vs the previous frame enqueued back to back, host waits for every frame's matches",
                 "value": round(n1 / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / n1 * 1e3, 4), "keypoints_per_frame": kp1,
                 "residency": "device-resident frames and results",
+                "cpu": cpu_points(frames_vga[:16], 500, "bf", 4.0, 4.0) if with_cpu else None,
                 "host_buffer_api": {"value": round(100 / dth, 1), "unit": "frames/s", "ms_per_frame": round(dth / 100 * 1e3, 4),
                                     "what": "ORBextractor.Extract + MatchByBruteForce on pageable host arrays (PCIe inclusive, python wrappers)"}})
 
@@ -415,10 +468,39 @@ def extra_configs(dev, frames_vga):
     dt = time.perf_counter() - t0
     kp3 = float(p.exs[0].last_counts(B3).mean())
     _, nm3 = p.fms[(p.n - 1) % S3].fetch_batch(counts_only=True)
+    # per-kernel exclusive times at this size: the same steps on one handle pair, one in flight, event pairs around every kernel
+    e3, m3 = p.exs[0], p.fms[0]
+    e3.set_profiling(True); m3.set_profiling(True)
+    for _ in range(6):
+        e3.extract_batch_dev(d3, B3, W3, H3, wait=False)
+        _, dd, dn, cap3 = e3.device_results()
+        m3.match_batch_dev(dd, cap3, cap3, dn, pairs3, L.MODE_KNN2_RATIO)
+        m3.sync()
+    t3 = dict(e3.kernel_times()); t3.update(m3.kernel_times())
+    e3.set_profiling(False); m3.set_profiling(False)
+    px3 = level_pixels(e3, W3, H3)
+    cnt3 = e3.last_counts(B3)
+    rows3 = [(int(cnt3[a]), int(cnt3[b])) for a, b in pairs3]
+    k3 = {k: {"avg_us": round(ms * 1e3 / max(n, 1), 2), "launches": n,
+              "alg_bytes_per_launch": int(algorithmic_bytes(k, B3, px3, int(cnt3.sum()), rows3))} for k, (ms, n) in t3.items()}
+    dom3 = max(k3, key=lambda k: k3[k]["avg_us"])
+    alg_step3 = B3 * (W3 * H3 + 3 * sum(px3)) + int(cnt3.sum()) * (1112 + 60)
+    roof3 = {"kernel": dom3, "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+             "achieved": round(k3[dom3]["alg_bytes_per_launch"] / (k3[dom3]["avg_us"] * 1e-6) / 1e9, 2),
+             "frac": round(k3[dom3]["alg_bytes_per_launch"] / (k3[dom3]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+             "avg_launch_us": k3[dom3]["avg_us"], "alg_bytes_per_launch": k3[dom3]["alg_bytes_per_launch"], "frames_per_launch": B3,
+             "timing": "hipEvent pair on the library's stream, one step in flight (exclusive)",
+             "rocprof_avg_launch_us": rocprof_avg_us(dom3, STATS_1080P_FILE),
+             "rocprof_source": "profiles/r3/r3_1080p_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --width 1920 --height 1080 --features 4000 --match-mode ratio --batch 32)",
+             "alg_bytes_per_frame": alg_step3 // B3,
+             "pipeline_frac": round(alg_step3 / (dt / n3) / 1e9 / HBM_PEAK_GBS, 5),
+             "kernels": k3}
     p.close()
     out.append({"config": "configs[2]: 1920x1080, 4000 features, 8 levels, extract + kNN2 ratio test vs previous frame, %d-frame steps, %d in flight" % (B3, S3),
                 "value": round(n3 * B3 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / n3 * 1e3, 4), "steps": n3,
-                "residency": "device-resident", "keypoints_per_frame": kp3, "matches_per_frame": round(float(nm3.mean()), 1)})
+                "residency": "device-resident", "keypoints_per_frame": kp3, "matches_per_frame": round(float(nm3.mean()), 1),
+                "roofline_1080p": roof3,
+                "cpu": cpu_points(f3, 4000, "ratio", 6.0, 6.0) if with_cpu else None})
 
     # ---- ORB extraction alone (BASELINE's metric names it at both sizes): the same pipelines without the matcher launches
     def extract_only(d, Bx, Wx, Hx, features, S, n):
@@ -664,6 +746,43 @@ def main():
         sync_all(); torch.cuda.synchronize()
         dts = time.perf_counter() - t1
         sustained = {"value": round(B * nsus / dts, 2), "unit": "frames/s", "steps": nsus, "seconds": round(dts, 3)}
+    # the same timed region with the matrix-core matcher selected (SSVIO_KERNEL_MFMA): identical outputs, reported BESIDE `value`,
+    # which stays the library's default kernel (k_hamming_knn2, the north-star kernel)
+    mfma_line = None
+    if mode >= 0:
+        profiling(False)
+        for m in fms: m.set_kernel("mfma")
+        for _ in range(S): step()
+        sync_all(); torch.cuda.synchronize()
+        if dist: dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps): step()
+        sync_all(); torch.cuda.synchronize()
+        dtm = time.perf_counter() - t1
+        if dist:
+            t = torch.tensor([dtm], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtm = float(t.item())
+        _, nmatch_m = fm.fetch_batch(counts_only=True)
+        mfma_line = {"value": round(total_frames / dtm, 2), "unit": "frames/s", "ms_per_step": round(dtm / args.steps * 1e3, 4), "steps": args.steps,
+                     "matches_per_frame": round(float(nmatch_m.mean()), 1),
+                     "what": "the same steps with ssvio_matcher_set_kernel(SSVIO_KERNEL_MFMA): k_hamming_knn2_mfma instead of k_hamming_knn2, bit-identical matches"}
+        if world == 1 and not args.no_extra_configs:
+            nsus = max(args.steps, int(1.2 / max(dtm / args.steps, 1e-6)) + 1)
+            t1 = time.perf_counter()
+            for _ in range(nsus): step()
+            sync_all(); torch.cuda.synchronize()
+            mfma_line["sustained"] = round(B * nsus / (time.perf_counter() - t1), 2)
+        profiling(True, only_fm="k_hamming_knn2")
+        inflight[0] = 1
+        for _ in range(5): step()
+        sync_all()
+        inflight[0] = S
+        tm = kernel_times().get("k_hamming_knn2")
+        if tm and tm[1]:
+            mfma_line["k_hamming_knn2_mfma_avg_us"] = round(tm[0] * 1e3 / tm[1], 2)
+        profiling(False)
+        for m in fms: m.set_kernel("valu")
     # the same steps again, one in flight, with event pairs around every kernel: the per-kernel table (exclusive times)
     profiling(False); profiling(True)
     inflight[0] = 1
@@ -687,21 +806,29 @@ def main():
     prof_ok = profiles_current() and (B, W, H, args.features) == (256, 640, 480, 1000)
     dom_avg_s = dom_ms * 1e-3 / dom_launches
     dom_bytes = algorithmic_bytes(dom, B, px, int(counts.sum()), pairs_rows)
-    achieved = dom_bytes / dom_avg_s / 1e9
+    excl_s = times[dom][0] * 1e-3 / times[dom][1]
+    achieved = dom_bytes / excl_s / 1e9
+    busy, cyc = valu_busy(dom, excl_s * 1e6) if prof_ok else (None, None)
+    alg_step = B * (W * H + 3 * sum(px)) + int(counts.sum()) * (1112 + 60)          # W*H + 3 P + N*(1112 + 60) per frame
     roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom) if prof_ok else None,
-            "traffic_source": "profiles/r2/r2_final_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, default batch); null when the "
-                              "kernel sources have changed since that profile (profiles/r2/r2_final_source_hash.txt)",
-            "avg_launch_us": round(dom_avg_s * 1e6, 2), "alg_bytes_per_launch": int(dom_bytes),
-            "avg_launch_note": "hipEvent pair around the kernel on its stream inside the timed region: with several steps in flight it includes "
-                               "the wait for CUs held by the other steps' kernels; exclusive_* is the same kernel with one step in flight",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "frac_note": "algorithmic bytes of one launch / the kernel's EXCLUSIVE launch time (hipEvent pair on the library's stream, one step in flight; "
+                         "rocprof_avg_launch_us is rocprofv3's figure for the same command) / 8 TB/s",
+            "traffic": pmc_traffic(dom) if prof_ok else None,
+            "traffic_source": "profiles/r3/r3_final_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, default batch); null when the "
+                              "kernel sources have changed since that profile (profiles/r3/r3_final_source_hash.txt)",
+            "avg_launch_us": round(excl_s * 1e6, 2), "alg_bytes_per_launch": int(dom_bytes),
             "rocprof_avg_launch_us": rocprof_avg_us(dom) if prof_ok else None,
-            "valu_busy": valu_busy(dom, times[dom][0] * 1e3 / times[dom][1]) if prof_ok else None,
-            "valu_busy_note": "VALU wave-instructions x 4 cycles over the SIMD cycles of the exclusive launch (2.4 GHz); an upper bound: and / or / add / sub "
-                              "issue in 2.4 cycles on this chip (profiles/r2/ubench_valu_table.txt), so a kernel built from them can read above 1",
-            "binds": "VALU issue, not HBM: the path is integer byte work with ~48 lane-instructions per pyramid pixel (DESIGN.md section 3); the HBM fraction is reported because the contract asks for it",
-            "exclusive_avg_launch_us": round(times[dom][0] * 1e3 / times[dom][1], 2),
-            "exclusive_frac": round(dom_bytes / (times[dom][0] * 1e-3 / times[dom][1]) / 1e9 / HBM_PEAK_GBS, 5)}
+            "in_flight_avg_launch_us": round(dom_avg_s * 1e6, 2),
+            "in_flight_frac": round(dom_bytes / dom_avg_s / 1e9 / HBM_PEAK_GBS, 5),
+            "in_flight_note": "hipEvent pair around the kernel inside the timed region: with several steps in flight it includes the wait for CUs "
+                              "held by the other steps' kernels",
+            "valu_busy": busy, "valu_issue_cycles_per_instruction": cyc,
+            "valu_busy_note": "SQ_INSTS_VALU x the kernel's average issue cycles (two measured issue classes weighted by its static instruction mix, "
+                              "profiles/r3/valu_mix.json) over the SIMD cycles of the exclusive launch at 2.4 GHz",
+            "pipeline_frac": round(alg_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+            "pipeline_note": "algorithmic bytes of a whole step (%d frames x %.2f MB) / ms_per_step / 8 TB/s" % (B, alg_step / B / 1e6),
+            "binds": "VALU issue, not HBM: the path is integer byte work with ~48 lane-instructions per pyramid pixel (DESIGN.md section 3); the HBM fraction is reported because the contract asks for it"}
     # the matcher is VALU-bound (xor+popcount), not HBM-bound: report its VALU fraction beside it
     if "k_hamming_knn2" in times:
         ms, launches = times["k_hamming_knn2"]
@@ -716,7 +843,7 @@ def main():
     trace('kernel table done')
     nxt = None if (args.no_next_rows or rank != 0) else next_rows(exs[0], fms[0], d_frames, B, W, H, pairs, dev)   # no collective inside: rank 0 only
     bm = None if args.no_batched_matching else batched_matching(rank, world, dev, dist)
-    xc = extra_configs(dev, frames) if (world == 1 and not args.no_extra_configs and (W, H) == (640, 480)) else None
+    xc = extra_configs(dev, frames, not args.no_cpu_baseline) if (world == 1 and not args.no_extra_configs and (W, H) == (640, 480)) else None
     if rank == 0:
         out = {
             "metric": "ORB extract + match frames/s (%s)" % ("BASELINE configs[1], VGA, device-resident" if (W, H, args.features, args.match_mode) == (640, 480, 1000, "bf")
@@ -740,6 +867,7 @@ def main():
             "kernel_events": {"roofline": "hipEvent pairs around %s in the timed region" % dom,
                               "kernels": "second pass of the same steps, one step in flight, pairs around every kernel (exclusive times)"},
             "host_waits": "per step" if args.sync_steps else "none inside the timed region (pipelined)",
+            "mfma_matcher": mfma_line,
             "batched_matching": bm,
             "next_rows": nxt,
         }
@@ -761,9 +889,9 @@ def main():
 
 if __name__ == "__main__":
     main()
-    # every handle is closed and the line is out: leave without the interpreter's and the HIP runtime's teardown.  (The hang seen
-    # at the end of one run in four turned out to be the bench's own: it destroyed the extractors before the matchers that ran on
-    # their streams; the order is fixed and the library no longer touches a borrowed stream at destroy.  The hard exit stays.)
+    # every handle is closed and the line is out: the process ends through the interpreter's and the HIP runtime's normal teardown,
+    # so that a fault or hang in it shows in the exit status.  (The hang once seen at the end of one run in four was the bench's own
+    # close order, fixed in round 2.)  SSVIO_BENCH_HARD_EXIT=1 skips the teardown.
     sys.stdout.flush(); sys.stderr.flush()
-    if not (os.environ.get("SSVIO_BENCH_SOFT_EXIT") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)):   # a profiler writes its files at exit
+    if os.environ.get("SSVIO_BENCH_HARD_EXIT"):
         os._exit(0)

@@ -45,6 +45,7 @@ public:
         int n = 0;
         status_ = ssvio_orb_extract(h_, img.ptr(0), img.cols, img.rows, (int)img.step, kp_.data(), desc_.data(), cap, &n);
         keypoints.clear();
+        if (status_ == SSVIO_OK && keepPyramid) fetchPyramid();                     // ComputePyramid runs before anything can return (:514)
         if (status_ != SSVIO_OK || n == 0) { descriptors.release(); return; }     // :526-527
         descriptors.create(n, 32, CV_8U);                                         // :530
         cv::Mat d = descriptors.getMat();
@@ -52,13 +53,14 @@ public:
         static_assert(sizeof(cv::KeyPoint) == sizeof(ssvio_keypoint), "cv::KeyPoint layout");
         std::memcpy((void*)keypoints.data(), kp_.data(), (size_t)n * sizeof(ssvio_keypoint));
         for (int i = 0; i < n; ++i) std::memcpy(d.ptr(i), desc_.data() + (size_t)i * 32, 32);
-        if (keepPyramid) fetchPyramid();
     }
 
-    // public member of the reference (include/Feature.h:45); never read outside Feature.cpp there, so it is
-    // only materialised when keepPyramid is set (costs a device->host copy per level)
+    // public member of the reference (include/Feature.h:45), filled by every Extract like there (src/Feature.cpp:514, :800-824):
+    // level l is the ROI at (19, 19) of a buffer with the 19-px BORDER_REFLECT_101 rim.  Nothing outside Feature.cpp reads it in
+    // the reference, and here it costs one device->host copy per level and call: a caller that never looks at it sets
+    // keepPyramid = false (interface table).
     std::vector<cv::Mat> mvImagePyramid;
-    bool keepPyramid = false;
+    bool keepPyramid = true;
 
     int inline GetLevels() { return nlevels; }
     float inline GetScaleFactor() { return (float)scaleFactor; }

@@ -35,8 +35,7 @@ int main(int argc, char** argv)
         FeatureMatching::Ptr fm = std::make_shared<FeatureMatching>("../vocabulary/orbvoc.dbow3", cfg);
         cv::Mat a(h, w, CV_8UC1, raw.data(), (size_t)w), b(h, w, CV_8UC1, raw.data() + (size_t)w * h, (size_t)w);
         std::vector<cv::KeyPoint> ka, kb; cv::Mat da, db;
-        orb->keepPyramid = true;
-        orb->Extract(a, cv::Mat(), ka, da);
+        orb->Extract(a, cv::Mat(), ka, da);                  // mvImagePyramid is filled by default, like the reference's (checked at the end)
         orb->Extract(b, cv::Mat(), kb, db);
         {   // a non-8UC1 image (the reference asserts, src/Feature.cpp:511): no exception, outputs empty, the status says why
             cv::Mat c3(h / 3, w, CV_8UC3, raw.data(), (size_t)w * 3);
@@ -152,9 +151,11 @@ int main(int argc, char** argv)
                     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 50;
                     printf("time %-28s %8.1f us per call\n", name, us);
                 };
-                orb->keepPyramid = false;
                 std::vector<cv::KeyPoint> kt; cv::Mat dt; std::vector<cv::DMatch> mt; ssvio::Correspondences ct;
-                timeit("ORBextractor::Extract", [&] { orb->Extract(b, cv::Mat(), kt, dt); });
+                timeit("ORBextractor::Extract", [&] { orb->Extract(b, cv::Mat(), kt, dt); });         // with mvImagePyramid (the default)
+                orb->keepPyramid = false;
+                timeit("Extract, keepPyramid=false", [&] { orb->Extract(b, cv::Mat(), kt, dt); });
+                orb->keepPyramid = true;
                 timeit("MatchByBruteForce", [&] { fm->MatchByBruteForce(db, da, mt); });
                 timeit("MatchByDBoW", [&] { fd->MatchByDBoW(db, da, mt); });
                 timeit("MatchByProject", [&] { fm->MatchByProject(p3, da, p2, db, radian, K, R, t, mt); });

@@ -1,11 +1,11 @@
 #!/bin/bash
-# usage (GPU box): tools/gpu_profile.sh <tag>
+# usage (GPU box): tools/gpu_profile.sh <tag> [extra bench.py arguments, e.g. --width 1920 --height 1080 --features 4000 --match-mode ratio --batch 32]
 #   1. rocprofv3 --kernel-trace --stats over the default bench command (per-kernel average durations)
 #   2. two --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs, MI355X_MICROARCH.md "HBM / rocprofv3") -> HBM traffic per launch
 # Results land in gpurun_out/<tag>_*; copy what should be judged into profiles/.
-tag=${1:-prof}; R=$GRAFT_REPO_ROOT
+tag=${1:-prof}; shift; R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp SSVIO_BENCH_SOFT_EXIT=1
-BENCH="$R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs --no-batched-matching --no-next-rows"
+BENCH="$R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs --no-batched-matching --no-next-rows $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -- python3 $BENCH > $R/gpurun_out/${tag}_trace.log 2>&1 || { tail -5 $R/gpurun_out/${tag}_trace.log; exit 1; }
 grep '"metric"' $R/gpurun_out/${tag}_trace.log > $R/gpurun_out/${tag}_bench_under_trace.json
 cp $(ls $R/gpurun_out/${tag}_trace/*/*kernel_stats.csv | tail -1) $R/gpurun_out/${tag}_kernel_stats.csv && head -14 $R/gpurun_out/${tag}_kernel_stats.csv
