@@ -112,8 +112,8 @@ int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs);           
 // larger ones are copied into d_q / d_t (capi_match.hip)
 int stage_pair(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, const uint8_t* t, int nt, int tstride, const uint8_t** d_q, const uint8_t** d_t);
 // the batched matcher in two steps, shared by the allocating entry points and the one that allocates nothing (capi_match.hip)
-struct MatchPlan { int maxRows, nChunks, chunkRows, nChunksR, chunkRowsR; bool small, smallRev, mfma; size_t partialEntries, partialRevEntries; };
-int match_plan(int maxQ, int maxT, int npairs, int mode, int kernel, size_t limitEntries, MatchPlan& p);
+struct MatchPlan { int maxRows, nChunks, chunkRows, nChunksR, chunkRowsR, qBlocks, qBlocksR; bool small, smallRev, mfma; size_t partialEntries, partialRevEntries; };
+int match_plan(int maxQ, int maxT, int npairs, int mode, int kernel, int slack, size_t limitEntries, MatchPlan& p);   // slack: rows at the end of a set that are rarely filled (32 for the extractor's sets, 0 for exact counts)
 int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
                  const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts, const int* d_pairs, int npairs, int maxQ, int maxT, int mode,
                  uint2* partial, uint2* partialRev, ssvio_dmatch* out, int* nout, int32_t* raw, bool profile);

@@ -19,13 +19,14 @@ int upload_rows(uint8_t* dst, const uint8_t* src, int n, int stride, std::vector
 // the chunk count -- not the chunk size -- is what this fixes; chunkRows is the upper bound for the partial lists' layout.
 // Query rows: a set handed over by the extractor holds up to 32 rows less than it can (the quadtree's overshoot slack); counting
 // query blocks without that slack keeps a block that will be empty out of the balance.
-static void pick_chunks(int maxQ, int maxT, int npairs, bool mfma, int& nChunks, int& chunkRows)
+static void pick_chunks(int maxQ, int maxT, int npairs, bool mfma, int slack, int& qBlocksOut, int& nChunks, int& chunkRows)
 {
     if (mfma) {
         // k_hamming_knn2_mfma: a workgroup expands its query rows into registers once (~100 instructions per 32 rows) and a chunk holds
         // at most kMfmaChunkRows rows; ~1024 workgroups (two per CU, two rounds) of at least 256 train rows each
         static const int targetM = [] { const char* e = getenv("SSVIO_MFMA_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
-        const long qBlocks = (long)knn2_mfma_query_blocks(maxQ) * npairs;
+        qBlocksOut = knn2_mfma_query_blocks(maxQ, slack);
+        const long qBlocks = (long)qBlocksOut * npairs;
         long want = (targetM + qBlocks / 2) / qBlocks;
         const long minChunks = (maxT + kMfmaChunkRows - 1) / kMfmaChunkRows, maxChunks = std::max<long>(minChunks, std::min<long>(64, maxT / 256));
         want = std::max(minChunks, std::min(want, maxChunks));
@@ -35,7 +36,8 @@ static void pick_chunks(int maxQ, int maxT, int npairs, bool mfma, int& nChunks,
     }
     static const int forcedRows = [] { const char* e = getenv("SSVIO_MATCH_CHUNKROWS"); return e ? atoi(e) : 0; }();   // tuning knob
     static const int target = [] { const char* e = getenv("SSVIO_MATCH_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
-    const long qBlocks = (long)knn2_query_blocks(maxQ) * npairs;
+    qBlocksOut = knn2_query_blocks(maxQ, slack);
+    const long qBlocks = (long)qBlocksOut * npairs;
     long want = (target + qBlocks / 2) / qBlocks;
     const long maxChunks = std::max(1, (maxT + 63) / 64);
     want = std::min<long>(std::min<long>(want, maxChunks), 64);
@@ -62,19 +64,20 @@ int upload_pairs(ssvio_matcher* m, const int32_t* pairs, int npairs)
 // how a batch of pairs is cut into launches: chunks of the train set (forward pass; reverse pass of the cross-check) and the
 // partial-list entries (uint2) they need.  limitEntries > 0 caps the scratch (the no-allocation entry point): chunks are
 // halved until both lists fit, SSVIO_ERR_CAPACITY if one chunk per pair does not.
-int match_plan(int maxQ, int maxT, int npairs, int mode, int kernel, size_t limitEntries, MatchPlan& p)
+int match_plan(int maxQ, int maxT, int npairs, int mode, int kernel, int slack, size_t limitEntries, MatchPlan& p)
 {
     p.maxRows = std::max(maxQ, maxT);
     p.mfma = kernel == SSVIO_KERNEL_MFMA || kernel == SSVIO_KERNEL_MFMA_ALL;
     const bool smallOk = kernel != SSVIO_KERNEL_MFMA_ALL;
-    pick_chunks(maxQ, maxT, npairs, p.mfma, p.nChunks, p.chunkRows);
+    p.qBlocksR = 0;
+    pick_chunks(maxQ, maxT, npairs, p.mfma, slack, p.qBlocks, p.nChunks, p.chunkRows);
     p.small = smallOk && knn2_small_applies(maxQ, maxT, npairs); p.smallRev = false;
     if (p.small) { p.nChunks = 1; p.chunkRows = maxT; }
     p.nChunksR = 0; p.chunkRowsR = 0;
     const bool rev = mode == SSVIO_MODE_CROSSCHECK || mode == SSVIO_MODE_CROSSCHECK_CV;
     if (mode == SSVIO_MODE_CROSSCHECK_CV) { p.nChunks = 1; p.chunkRows = maxT; p.small = false; }     // no forward search: the forward list holds the votes
     if (rev) {
-        pick_chunks(maxT, maxQ, npairs, p.mfma, p.nChunksR, p.chunkRowsR);
+        pick_chunks(maxT, maxQ, npairs, p.mfma, slack, p.qBlocksR, p.nChunksR, p.chunkRowsR);
         p.smallRev = smallOk && knn2_small_applies(maxT, maxQ, npairs);
         if (p.smallRev) { p.nChunksR = 1; p.chunkRowsR = maxQ; }
     }
@@ -118,7 +121,7 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
     const bool needSecond = mode == SSVIO_MODE_KNN2_RATIO || mode == 3;
     if (mode != SSVIO_MODE_CROSSCHECK_CV) {
         ProfScope ps(prof, "k_hamming_knn2", s);
-        if (p.small) launch_knn2_small(a, maxQ, npairs, s); else if (p.mfma) launch_knn2_mfma(a, maxQ, npairs, needSecond, s); else launch_knn2(a, maxQ, npairs, s);
+        if (p.small) launch_knn2_small(a, maxQ, npairs, s); else if (p.mfma) launch_knn2_mfma(a, maxQ, p.qBlocks, npairs, needSecond, s); else launch_knn2(a, maxQ, p.qBlocks, npairs, s);
         SSVIO_HIP(hipGetLastError());
     }
     FinalizeArgs f{};
@@ -134,7 +137,7 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
         r.nChunks = p.nChunksR; r.chunkRows = p.chunkRowsR; r.partial = partialRev;
         {
             ProfScope ps(prof, "k_hamming_knn2", s);
-            if (p.smallRev) launch_knn2_small(r, maxT, npairs, s); else if (p.mfma) launch_knn2_mfma(r, maxT, npairs, false, s); else launch_knn2(r, maxT, npairs, s);
+            if (p.smallRev) launch_knn2_small(r, maxT, npairs, s); else if (p.mfma) launch_knn2_mfma(r, maxT, p.qBlocksR, npairs, false, s); else launch_knn2(r, maxT, p.qBlocksR, npairs, s);
             SSVIO_HIP(hipGetLastError());
         }
         f.partialRev = partialRev; f.nChunksRev = p.nChunksR;
@@ -151,11 +154,11 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
 static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, const int* d_qcounts,
                      const uint8_t* d_tdesc, int tStrideRows, const int* d_tcounts,
                      const int* d_pairs, int npairs, int maxQ, int maxT, int mode,
-                     ssvio_dmatch* outTo = nullptr, int* noutTo = nullptr, int32_t* rawTo = nullptr)
+                     ssvio_dmatch* outTo = nullptr, int* noutTo = nullptr, int32_t* rawTo = nullptr, int slack = 32)
 {
     hipStream_t s = m->stream;
     MatchPlan p;
-    int rc = match_plan(maxQ, maxT, npairs, mode, m->kernel, 0, p); if (rc) return rc;
+    int rc = match_plan(maxQ, maxT, npairs, mode, m->kernel, slack, 0, p); if (rc) return rc;
     rc = grow(m->d_partial, m->partialCap, p.partialEntries, s); if (rc) return rc;
     rc = grow(m->d_nout, m->noutCap, (size_t)npairs, s); if (rc) return rc;
     if (mode == 3) { rc = grow(m->d_raw, m->rawCap, (size_t)npairs * 3 * p.maxRows, s); if (rc) return rc; }
@@ -171,7 +174,8 @@ static int match_run(ssvio_matcher* m, const uint8_t* d_qdesc, int qStrideRows, 
 // the batched matcher over a pair list that is already in m->d_pairs (capi_loop.hip builds it on the device)
 int match_batch_on_device_pairs(ssvio_matcher* m, const uint8_t* d_desc, int strideRows, const int* d_counts, int npairs, int maxRows, int mode)
 {
-    const int rc = match_run(m, d_desc, strideRows, d_counts, d_desc, strideRows, d_counts, m->d_pairs, npairs, maxRows, maxRows, mode);
+    const int rc = match_run(m, d_desc, strideRows, d_counts, d_desc, strideRows, d_counts, m->d_pairs, npairs, maxRows, maxRows, mode,
+                             nullptr, nullptr, nullptr, /*slack=*/0);          // key-frame sets of a loop-candidate walk: as full as they say
     if (rc) return rc;
     m->lastHadPairs = true;
     return SSVIO_OK;
@@ -240,7 +244,7 @@ static int match_host(ssvio_matcher* m, const uint8_t* q, int nq, int qstride, c
     m->h_counts2[0] = nq; m->h_counts2[1] = nt;
     *(volatile int*)m->h_result = 0;
     rc = match_run(m, d_qrows, 0, m->d_counts2m, d_trows, 0, m->d_counts2m + 1, nullptr, 1, nq, nt, mode,
-                   (ssvio_dmatch*)(m->d_resultm + 16), (int*)m->d_resultm, (int32_t*)(m->d_resultm + 16));
+                   (ssvio_dmatch*)(m->d_resultm + 16), (int*)m->d_resultm, (int32_t*)(m->d_resultm + 16), /*slack=*/0);
     if (rc) return rc;
     SSVIO_HIP(hipStreamSynchronize(s));
     if (mode == 3) {

@@ -49,7 +49,7 @@ extern "C" int ssvio_match_batch_dev_noalloc(ssvio_matcher* m, const void* d_des
     }
     if (!base) { set_error("fixed scratch of device %d was not set up", m->device); return SSVIO_ERR_INVALID; }
     MatchPlan p;
-    const int rc = match_plan(max_rows, max_rows, npairs, mode, m->kernel, (size_t)SSVIO_NOALLOC_SCRATCH_BYTES / sizeof(uint2), p);
+    const int rc = match_plan(max_rows, max_rows, npairs, mode, m->kernel, 32, (size_t)SSVIO_NOALLOC_SCRATCH_BYTES / sizeof(uint2), p);
     if (rc) return rc;                                           // SSVIO_ERR_CAPACITY: beyond the fixed scratch, nothing was launched
     SSVIO_HIP(hipSetDevice(m->device));
     uint2* partial = (uint2*)base;

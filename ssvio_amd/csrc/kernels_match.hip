@@ -201,17 +201,18 @@ int knn2_queries_per_lane(int maxQ)
 }
 
 // query blocks of a launch: those the sets are expected to fill.  A set handed over by the extractor can hold 32 rows more than it
-// normally does (the quadtree's overshoot slack, 4 per level); the kernel walks on to rows beyond the grid, so this is only balance
-int knn2_query_blocks(int maxQ)
+// normally does (the quadtree's overshoot slack, 4 per level; slack = 32 from the batched entry points); the kernel walks on to rows
+// beyond the grid, so this is only balance.  Single pairs from the host are exactly as long as they say (slack = 0).
+int knn2_query_blocks(int maxQ, int slack)
 {
     const int R = knn2_queries_per_lane(maxQ);
-    return (std::max(maxQ - 32, 1) + 256 * R - 1) / (256 * R);
+    return (std::max(maxQ - slack, 1) + 256 * R - 1) / (256 * R);
 }
 
-void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s)
+void launch_knn2(const MatchArgs& a, int maxQ, int qBlocks, int npairs, hipStream_t s)
 {
     const int R = knn2_queries_per_lane(maxQ);
-    dim3 grid(knn2_query_blocks(maxQ), a.nChunks, npairs);
+    dim3 grid(qBlocks, a.nChunks, npairs);
     if (R == 4) hipLaunchKernelGGL(k_hamming_knn2<4>, grid, dim3(256), 0, s, a);
     else if (R == 2) hipLaunchKernelGGL(k_hamming_knn2<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_hamming_knn2<1>, grid, dim3(256), 0, s, a);

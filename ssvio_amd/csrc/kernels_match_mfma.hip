@@ -253,10 +253,10 @@ int knn2_mfma_groups(int maxQ)
     return 2;
 }
 
-int knn2_mfma_query_blocks(int maxQ)
+int knn2_mfma_query_blocks(int maxQ, int slack)
 {
     const int qwg = 4 * knn2_mfma_groups(maxQ) * 32;
-    return (std::max(maxQ - 32, 1) + qwg - 1) / qwg;
+    return (std::max(maxQ - slack, 1) + qwg - 1) / qwg;
 }
 
 template <bool SECOND>
@@ -267,10 +267,10 @@ static void launch_mfma_g(const MatchArgs& a, int G, dim3 grid, hipStream_t s)
 }
 
 // needSecond = false: only the nearest neighbour is searched (the second key of every partial entry is kKeyInit)
-void launch_knn2_mfma(const MatchArgs& a, int maxQ, int npairs, bool needSecond, hipStream_t s)
+void launch_knn2_mfma(const MatchArgs& a, int maxQ, int qBlocks, int npairs, bool needSecond, hipStream_t s)
 {
     const int G = knn2_mfma_groups(maxQ);
-    dim3 grid(knn2_mfma_query_blocks(maxQ), a.nChunks, npairs);
+    dim3 grid(qBlocks, a.nChunks, npairs);
     if (needSecond) launch_mfma_g<true>(a, G, grid, s); else launch_mfma_g<false>(a, G, grid, s);
 }
 

@@ -110,16 +110,16 @@ void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, 
 
 void launch_pair_summary(const ssvio_dmatch* out, const int* nout, int maxRows, const int* pairs, int npairs, int idMode, int idBase,
                          ssvio_pair_summary* rec, hipStream_t s);
-void launch_knn2(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);
+void launch_knn2(const MatchArgs& a, int maxQ, int qBlocks, int npairs, hipStream_t s);   // qBlocks = knn2_query_blocks(maxQ, slack)
 bool knn2_small_applies(int maxQ, int maxT, int npairs);                 // small single pairs: chunks = the waves of one workgroup, no merge launch
 void launch_knn2_small(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);   // writes partial[pair][q] (nChunks = 1, pair stride maxRows)
-int  knn2_query_blocks(int maxQ);           // grid.x of k_hamming_knn2 for sets of up to maxQ rows
+int  knn2_query_blocks(int maxQ, int slack); // grid.x of k_hamming_knn2 for sets of up to maxQ rows of which the last `slack` are rarely filled
 int  knn2_queries_per_lane(int maxQ);       // R of k_hamming_knn2<R> for this many query rows (tuning knob: SSVIO_MATCH_R)
 void launch_finalize(const FinalizeArgs& a, int npairs, int maxQ, int maxT, hipStream_t s);
 // the same 2-NN on the matrix cores (kernels_match_mfma.hip): exact int8 contraction, selectable per handle
 constexpr int kMfmaChunkRows = 8160;        // most train rows a chunk of k_hamming_knn2_mfma can hold (13-bit row field, 32-row tiles)
-void launch_knn2_mfma(const MatchArgs& a, int maxQ, int npairs, bool needSecond, hipStream_t s);   // needSecond = false: nearest neighbour only
-int  knn2_mfma_query_blocks(int maxQ);      // grid.x of k_hamming_knn2_mfma for sets of up to maxQ rows
+void launch_knn2_mfma(const MatchArgs& a, int maxQ, int qBlocks, int npairs, bool needSecond, hipStream_t s);   // needSecond = false: nearest neighbour only
+int  knn2_mfma_query_blocks(int maxQ, int slack);      // grid.x of k_hamming_knn2_mfma for sets of up to maxQ rows
 
 #if defined(__HIPCC__)
 constexpr unsigned kKeyInit = 0xFFFFFFFFu;     // "no candidate yet" in the (dist << 23 | trainIdx) key order

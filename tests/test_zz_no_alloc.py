@@ -27,8 +27,16 @@ def _both(fm, torch, L, buf, counts, stride, max_rows, pairs, mode):
     d_out = torch.full((len(pairs), max_rows, 4), -7, dtype=torch.int32, device="cuda")
     d_n = torch.full((len(pairs),), -7, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    fm.match_batch_dev_noalloc(d_desc, stride, max_rows, d_cnt, d_pairs, len(pairs), mode, d_out, d_n)
+    # the property the entry point exists for: it allocates nothing.  Every growing allocation of the library is made to fail while
+    # it runs, and the device's free memory must not move across it
+    free0 = torch.cuda.mem_get_info()[0]
+    L.lib().ssvio_test_fail_next_allocs(1 << 20)
+    try:
+        fm.match_batch_dev_noalloc(d_desc, stride, max_rows, d_cnt, d_pairs, len(pairs), mode, d_out, d_n)
+    finally:
+        L.lib().ssvio_test_fail_next_allocs(0)
     fm.sync()
+    assert torch.cuda.mem_get_info()[0] == free0, "the no-allocation entry point changed the device's free memory"
     got = d_out.cpu().numpy().view(L.DM_DTYPE).reshape(len(pairs), max_rows)
     return want, want_n, got, d_n.cpu().numpy()
 
