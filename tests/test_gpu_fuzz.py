@@ -80,6 +80,7 @@ def test_random_match_shapes_equal_oracle(nq, nt, seed):
         t[nt // 2:] = t[:nt - nt // 2]                               # duplicated rows: lowest-index ties
     th, ratio = [(50, 0.6), (30, 0.8), (80, 0.95)][seed % 3]
     fm = S.FeatureMatching(None, {"Threshold": th, "NNRatio": ratio})
+    fm.set_kernel("mfma_all" if seed % 2 else "valu")               # both 2-NN kernels see half of the cases
     b = lambda a: np.ascontiguousarray(a).view(np.uint8)
     idx, d1, d2 = fm.knn2_raw(q, t)
     ri, r1, r2 = O.knn2_raw(q, t)
@@ -90,8 +91,9 @@ def test_random_match_shapes_equal_oracle(nq, nt, seed):
     fm.close()
 
 
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
 @pytest.mark.parametrize("seed,mode", [(1, 0), (2, 1), (3, 2), (4, 0), (5, 4)])
-def test_ragged_batches_equal_oracle(seed, mode):
+def test_ragged_batches_equal_oracle(seed, mode, kernel):
     """device-resident batch with sets of very different sizes (including empty ones) and repeated / self pairs"""
     import torch
     import ssvio_amd as S
@@ -110,6 +112,7 @@ def test_ragged_batches_equal_oracle(seed, mode):
         buf[s, :len(d)] = d
     pairs = np.array([[rng.integers(0, nsets), rng.integers(0, nsets)] for _ in range(14)] + [[0, 0], [3, 3]], np.int32)
     fm = S.FeatureMatching(None, {"Threshold": 50, "NNRatio": 0.6})
+    fm.set_kernel(kernel)
     d_desc = torch.from_numpy(buf).cuda(); d_cnt = torch.tensor(counts, dtype=torch.int32).cuda()
     fm.match_batch_dev(d_desc, stride, stride, d_cnt, pairs, mode)
     fm.sync()
@@ -185,6 +188,7 @@ def test_one_matcher_handle_across_changing_shapes_and_modes():
     refs = {0: O.match_bruteforce, 1: lambda a, c: O.match_knn2_ratio(a, c, 50, 0.6), 2: O.match_crosscheck, 4: O.match_crosscheck_cv}
     for it in range(40):
         mode = int(rng.choice([0, 1, 2, 4]))
+        fm.set_kernel(["valu", "mfma", "mfma_all"][it % 3])      # the kernels alternate on the same handle and buffers
         nsets = int(rng.integers(2, 7))
         stride = int(rng.choice([64, 300, 1032, 2100, 3000]))
         counts = [int(min(stride, c)) for c in rng.choice([0, 1, 5, 63, 64, 65, 200, 513, 1006, 2049, 3000], nsets)]
