@@ -468,6 +468,19 @@ def extra_configs(dev, frames_vga, with_cpu=True):
     dt = time.perf_counter() - t0
     kp3 = float(p.exs[0].last_counts(B3).mean())
     _, nm3 = p.fms[(p.n - 1) % S3].fetch_batch(counts_only=True)
+    # the same steps with the matrix-core matcher (identical match lists)
+    for m in p.fms: m.set_kernel("mfma")
+    for _ in range(S3):
+        p.step(d3, B3, W3, H3, pairs3, L.MODE_KNN2_RATIO)
+    p.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n3):
+        p.step(d3, B3, W3, H3, pairs3, L.MODE_KNN2_RATIO)
+    p.sync(); torch.cuda.synchronize()
+    dt3m = time.perf_counter() - t0
+    _, nm3m = p.fms[(p.n - 1) % S3].fetch_batch(counts_only=True)
+    assert np.array_equal(nm3, nm3m), "the two matcher kernels disagree"
+    for m in p.fms: m.set_kernel("valu")
     # per-kernel exclusive times at this size: the same steps on one handle pair, one in flight, event pairs around every kernel
     e3, m3 = p.exs[0], p.fms[0]
     e3.set_profiling(True); m3.set_profiling(True)
@@ -499,6 +512,8 @@ def extra_configs(dev, frames_vga, with_cpu=True):
     out.append({"config": "configs[2]: 1920x1080, 4000 features, 8 levels, extract + kNN2 ratio test vs previous frame, %d-frame steps, %d in flight" % (B3, S3),
                 "value": round(n3 * B3 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / n3 * 1e3, 4), "steps": n3,
                 "residency": "device-resident", "keypoints_per_frame": kp3, "matches_per_frame": round(float(nm3.mean()), 1),
+                "mfma_matcher": {"value": round(n3 * B3 / dt3m, 1), "unit": "frames/s", "ms_per_step": round(dt3m / n3 * 1e3, 4),
+                                 "what": "the same steps with ssvio_matcher_set_kernel(SSVIO_KERNEL_MFMA); identical match counts"},
                 "roofline_1080p": roof3,
                 "cpu": cpu_points(f3, 4000, "ratio", 6.0, 6.0) if with_cpu else None})
 
