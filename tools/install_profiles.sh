@@ -1,4 +1,4 @@
 #!/bin/bash
-# usage (here, after tools/gpu_final.sh on the GPU box): copies the merged gpurun_out/r2_* results into profiles/r2/
-cd "$(dirname "$0")/.." && cd gpurun_out && cp r2_final_kernel_stats.csv r2_final_pmc_hbm.json r2_final_pmc_sq.txt r2_final_pmc_lds.txt r2_final_source_hash.txt \
-   r2_bench_default.json r2_bench_200steps.json r2_trace_by_batch_size.txt ../profiles/r2/ && cp r2_final_bench_under_trace.json ../profiles/r2/r2_final_bench_under_rocprof.json && echo installed
+# usage (here, after tools/gpu_final.sh on the GPU box): copies the merged gpurun_out/r3_* results into profiles/r3/
+cd "$(dirname "$0")/.." && cd gpurun_out && cp r3_final_kernel_stats.csv r3_final_pmc_hbm.json r3_final_pmc_sq.txt r3_final_pmc_lds.txt r3_final_source_hash.txt \
+   r3_bench_default.json r3_bench_200steps.json r3_trace_by_batch_size.txt ../profiles/r3/ && cp r3_final_bench_under_trace.json ../profiles/r3/r3_final_bench_under_rocprof.json && cp r3_mfma_probe.txt r3_mfma_pmc.txt r3_valu_pmc.txt r3_1080p_kernel_stats.csv r3_1080p_pmc_hbm.json ../profiles/r3/ && echo installed
