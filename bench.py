@@ -223,6 +223,15 @@ def cpu_points(frames, nfeatures, match_mode, b1, bn):
     return {"one_thread": cpu_baseline(frames, nfeatures, match_mode, b1), "all_cores": cpu_baseline_all_cores(frames, nfeatures, match_mode, bn)}
 
 
+def mfma_roofline(pairs_per_s, world):
+    """k_hamming_knn2_mfma against the dense int8 matrix peak: a descriptor pair is 256 multiply-adds = 512 ops"""
+    peak = MFMA_PEAK_PAIRS * 512 / 1e12 * world
+    ach = pairs_per_s * 512 / 1e12
+    return {"kernel": "k_hamming_knn2_mfma", "bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TOP/s", "frac": round(ach / peak, 4),
+            "peak_source": "1024 SIMDs x one v_mfma_i32_32x32x32_i8 (65 536 int8 ops) per 32 cycles x 2.4 GHz = 5.03 POP/s dense (MI355X_MICROARCH.md, matrix table: int8 = 2 x bf16); "
+                           "whole-call time (both directions of a cross-check, merge, filter and summary launches included), so the kernel alone is higher"}
+
+
 def batched_matching(rank, world, dev, dist, iters=10):
     """BASELINE configs 4 and 5 through ssvio_amd.dist -- the package code an 8-GPU run executes and that
     tests/test_dist_gloo.py (gloo, world 2) and tests/test_gpu_dist.py (one MI355X, vs the oracle) cover: keyframe-pair blocks dealt
@@ -279,7 +288,8 @@ def batched_matching(rank, world, dev, dist, iters=10):
                 "ms": round(dt * 1e3, 4), "descriptor_pairs_per_s": 2.0 * nkf * rows * rows / dt,
                 "query_matches_per_s": total / dt, "matches": total,
                 "mfma_kernel": {"kernel": "k_hamming_knn2_mfma (SSVIO_KERNEL_MFMA: exact int8 contraction, same results)", "ms": round(dtm * 1e3, 4),
-                                "descriptor_pairs_per_s": 2.0 * nkf * rows * rows / dtm, "matches": totalm, "speedup": round(dt / dtm, 3)}})
+                                "descriptor_pairs_per_s": 2.0 * nkf * rows * rows / dtm, "matches": totalm, "speedup": round(dt / dtm, 3),
+                                "roofline": mfma_roofline(2.0 * nkf * rows * rows / dtm, world)}})
 
     # ---- config 5 (timed subset, stated): loop-candidate all-pairs over 64 of the 4096 keyframes, 8000 descriptors each:
     # 2016 pair-blocks of 8000 x 8000 walked in super-blocks of 8 x 8 keyframes (36 tiles dealt to the ranks), per-pair summary
@@ -317,9 +327,8 @@ def batched_matching(rank, world, dev, dist, iters=10):
                 "valu_frac": round(float(npairs5) * rows5 * rows5 / dt5 / (world * VALU_PEAK_PAIRS), 4),
                 "mfma_kernel": {"kernel": "k_hamming_knn2_mfma (SSVIO_KERNEL_MFMA), identical records", "ms": round(dt5m * 1e3, 4),
                                 "descriptor_pairs_per_s": float(npairs5) * rows5 * rows5 / dt5m, "speedup": round(dt5 / dt5m, 3),
-                                "mfma_frac": round(float(npairs5) * rows5 * rows5 / dt5m / (world * MFMA_PEAK_PAIRS), 4),
-                                "mfma_frac_note": "of 1024 SIMDs x one v_mfma_i32_32x32x32_i8 (1024 descriptor-pair bits x 32) per 32 cycles at 2.4 GHz = 9.83e12 pairs/s; "
-                                                  "the chip holds ~2.05 GHz under this kernel (GRBM_GUI_ACTIVE, profiles/r3/mfma_*)"},
+                                "roofline": mfma_roofline(float(npairs5) * rows5 * rows5 / dt5m, world),
+                                "clock_note": "the chip holds ~2.07 GHz under this kernel (GRBM_GUI_ACTIVE, profiles/r3/r3_mfma_pmc.txt), the peak is priced at the nominal 2.4"},
                 "full_config_measured_1gpu": "profiles/r3/config5_full_1gpu.json: all 8 386 560 pair-blocks on ONE MI355X, 249.1 s (VALU kernel) / 74.3 s (MFMA kernel)",
                 "full_config_extrapolated_s": round(dt5 * (4096 * 4095 / 2) / npairs5 * world / 8, 1),
                 "full_config_note": "8 386 560 pair-blocks on 8 GPUs at this per-GPU rate (VALU kernel)"})

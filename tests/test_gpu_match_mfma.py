@@ -27,6 +27,16 @@ def fm(mods):
     m.close()
 
 
+def test_kernel_selection_is_validated(mods):
+    torch, S, synth, L, O = mods
+    m = S.FeatureMatching(None, {})
+    assert m.get_kernel() == "valu"                       # the default stays the xor / popcount kernel
+    with pytest.raises(S.SsvioError):
+        m.set_kernel(7)
+    m.set_kernel("mfma"); assert m.get_kernel() == "mfma"
+    m.close()
+
+
 def _all_modes(fm, O, q, t):
     idx, d1, d2 = fm.knn2_raw(q, t)
     ri, r1, r2 = O.knn2_raw(q, t)
