@@ -40,6 +40,7 @@ public:
         // assert(image.type() == CV_8UC1), :511 (active in the reference's Release build: it aborts).  The adapter does not throw
         // across the reference's exception-free interface: outputs empty, lastStatus() = SSVIO_ERR_INVALID.
         if (img.type() != CV_8UC1) { status_ = SSVIO_ERR_INVALID; keypoints.clear(); descriptors.release(); return; }
+        if (keepPyramid != exporting_) { ssvio_orb_set_export_pyramid(h_, keepPyramid ? 1 : 0); exporting_ = keepPyramid; }
         const int cap = ssvio_orb_max_keypoints(h_);
         kp_.resize(cap); desc_.resize((size_t)cap * 32);
         int n = 0;
@@ -57,8 +58,8 @@ public:
 
     // public member of the reference (include/Feature.h:45), filled by every Extract like there (src/Feature.cpp:514, :800-824):
     // level l is the ROI at (19, 19) of a buffer with the 19-px BORDER_REFLECT_101 rim.  Nothing outside Feature.cpp reads it in
-    // the reference, and here it costs one device->host copy per level and call: a caller that never looks at it sets
-    // keepPyramid = false (interface table).
+    // the reference; here a kernel stores the levels into pinned host memory beside the FAST / quadtree stages (a few microseconds
+    // per call at VGA): a caller that never looks at it may set keepPyramid = false (interface table).
     std::vector<cv::Mat> mvImagePyramid;
     bool keepPyramid = true;
 
@@ -76,13 +77,11 @@ protected:
     void fetchPyramid()
     {
         for (int l = 0; l < nlevels; ++l) {
-            int w = 0, h = 0;
-            if (ssvio_orb_pyramid_level(h_, 0, l, nullptr, 0, &w, &h) != SSVIO_OK) return;
-            whole_.resize(nlevels);
-            whole_[l].create(h + 38, w + 38, CV_8UC1);
-            ssvio_orb_pyramid_level(h_, 0, l, whole_[l].ptr(0), (int)whole_[l].step, &w, &h);
-            // the reference's entry is the ROI at (19,19) of the padded buffer (src/Feature.cpp:806-808)
-            mvImagePyramid[l] = cv::Mat(h, w, CV_8UC1, whole_[l].ptr(19) + 19, whole_[l].step);
+            const uint8_t* base = nullptr; int stride = 0, w = 0, h = 0;
+            if (ssvio_orb_exported_pyramid_level(h_, l, &base, &stride, &w, &h) != SSVIO_OK) return;
+            // the reference's entry is the ROI at (19,19) of the padded buffer (src/Feature.cpp:806-808); the buffer is the handle's
+            // pinned host memory, rewritten by the next Extract exactly as the reference rewrites its own
+            mvImagePyramid[l] = cv::Mat(h, w, CV_8UC1, const_cast<uint8_t*>(base) + (size_t)19 * stride + 19, (size_t)stride);
         }
     }
     int nfeatures; double scaleFactor; int nlevels; int iniThFAST; int minThFAST;
@@ -91,5 +90,5 @@ protected:
     ssvio_orb* h_ = nullptr;
     int status_ = SSVIO_OK;
     std::vector<ssvio_keypoint> kp_; std::vector<uint8_t> desc_;
-    std::vector<cv::Mat> whole_;
+    bool exporting_ = false;
 };

@@ -126,6 +126,14 @@ int  ssvio_orb_last_counts(ssvio_orb* h, int batch, int* n);
  * keep it; it is synthesised here on request. */
 int  ssvio_orb_pyramid_level(ssvio_orb* h, int frame, int level, uint8_t* dst, int dst_stride, int* lw, int* lh);
 
+/* The same, produced WITH the call instead of fetched after it (what the C++ adapter uses to fill mvImagePyramid on every Extract,
+ * as the reference does, src/Feature.cpp:514, :800-824): once enabled, every single-frame host call (ssvio_orb_extract[_rgb]) also
+ * stores the rimmed levels of its frame into pinned host memory owned by the handle -- a kernel writes them across the bus beside
+ * the FAST / quadtree stages, no copy commands -- and ssvio_orb_exported_pyramid_level hands out level `level`: *base = the rimmed
+ * image ((lh + 38) rows of *stride bytes; the level itself starts at base + 19 * stride + 19).  Valid until the handle's next call. */
+int  ssvio_orb_set_export_pyramid(ssvio_orb* h, int enable);
+int  ssvio_orb_exported_pyramid_level(ssvio_orb* h, int level, const uint8_t** base, int* stride, int* lw, int* lh);
+
 /* stage-level taps for parity tests (last call, frame `frame`) */
 int  ssvio_orb_debug_level_image(ssvio_orb* h, int frame, int level, int blurred, uint8_t* dst, int dst_stride);
 /* candidates before the quadtree: x,y relative to (minBorderX,minBorderY), response; returns count via *n */

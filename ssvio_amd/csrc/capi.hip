@@ -191,6 +191,10 @@ struct ssvio_orb {
     uint8_t* h_landing = nullptr; uint8_t* d_landing = nullptr; size_t landingCap = 0;
     ssvio_keypoint* hostKp = nullptr; uint8_t* hostDesc = nullptr;      // set around one call; device addresses inside d_landing
     uint8_t* h_inMapped = nullptr; uint8_t* d_inMapped = nullptr; size_t inMappedCap = 0;   // small inputs: k_level0 reads the frame from mapped host memory
+    // mvImagePyramid of the host single-frame calls (ssvio_orb_set_export_pyramid): k_export_pyramid stores the rimmed levels here
+    bool exportPyr = false, exportNow = false, exportValid = false;
+    uint8_t* h_pyrExp = nullptr; uint8_t* d_pyrExp = nullptr; size_t pyrExpCap = 0; ExportLayout expLay{}; int expW = 0, expH = 0;
+    hipEvent_t evExp = nullptr;
     KernelProfiler prof; std::string profOnly;
     std::unique_ptr<WorkerPool> pool;
     int lastBatch = 0;
@@ -427,6 +431,13 @@ static int orb_enqueue(ssvio_orb* h, int batch)
             launch_blur(h->d_pyr, h->d_blur, g.frameBytes, h->kl, g.blurStripsPerFrame, batch, h->side);
         }
         SSVIO_HIP(hipEventRecord(h->evJoin, h->side));
+        if (h->exportNow) {      // behind the blur on the side stream: nothing on the device waits for it, the call's end does
+            int maxRows = 0;
+            for (int l = 0; l < g.nlevels; ++l) maxRows = std::max(maxRows, g.lv[l].h + 2 * kEdge);
+            ProfScope p(h->prof, "k_export_pyramid", h->side);
+            launch_export_pyramid(h->d_pyr, h->kl, h->expLay, maxRows, h->d_pyrExp, h->side);
+            SSVIO_HIP(hipEventRecord(h->evExp, h->side));
+        }
         return SSVIO_OK;
     };
     if (!lateFork) { const int rc = fork_blur(); if (rc) return rc; }
@@ -453,7 +464,32 @@ static int orb_enqueue(ssvio_orb* h, int batch)
         launch_describe(h->d_pyr, h->d_blur, g.frameBytes, h->kl, h->d_sel, h->d_selCount, h->kpCap, h->kpCap, h->d_kpOut, h->d_desc,
                         h->d_kpCount, h->d_kpCountHost, h->hostKp, h->hostDesc, batch, s);
     }
+    if (h->exportNow) SSVIO_HIP(hipStreamWaitEvent(s, h->evExp, 0));
     SSVIO_HIP(hipGetLastError());                                 // a refused launch configuration shows up only here
+    return SSVIO_OK;
+}
+
+// the mapped host area of the exported pyramid for the current geometry
+static int orb_ensure_export(ssvio_orb* h)
+{
+    const PyramidGeom& g = h->geom;
+    if (h->expW == g.width && h->expH == g.height && h->h_pyrExp) return SSVIO_OK;
+    size_t off = 0;
+    for (int l = 0; l < g.nlevels; ++l) {
+        h->expLay.stride[l] = (g.lv[l].w + 2 * kEdge + 63) & ~63;
+        h->expLay.offset[l] = off;
+        off += (size_t)h->expLay.stride[l] * (g.lv[l].h + 2 * kEdge);
+        off = (off + 255) & ~(size_t)255;
+    }
+    if (off > h->pyrExpCap) {
+        SSVIO_HIP(hipStreamSynchronize(h->stream));
+        hfree(h->h_pyrExp); h->pyrExpCap = 0; h->d_pyrExp = nullptr;
+        SSVIO_HIP(hipHostMalloc((void**)&h->h_pyrExp, off, hipHostMallocMapped));
+        SSVIO_HIP(hipHostGetDevicePointer((void**)&h->d_pyrExp, h->h_pyrExp, 0));
+        h->pyrExpCap = off;
+    }
+    if (!h->evExp) SSVIO_HIP(hipEventCreateWithFlags(&h->evExp, hipEventDisableTiming));
+    h->expW = g.width; h->expH = g.height;
     return SSVIO_OK;
 }
 
@@ -473,7 +509,7 @@ static int orb_run(ssvio_orb* h, int batch, bool wait = true)
     hipStream_t s = h->stream;
     h->hostRawValid = false;
     bool launched = false;
-    if (graphs_enabled() && !h->hostQuadtree && !h->prof.enabled && !h->graphFailed && !h->hostKp) {
+    if (graphs_enabled() && !h->hostQuadtree && !h->prof.enabled && !h->graphFailed && !h->hostKp && !h->exportNow) {
         if (!h->gexec || h->gBatch != batch || h->gGen != h->allocGen) {
             if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
             quadtree_prepare();                                   // function attributes are set outside the capture
@@ -560,6 +596,8 @@ void ssvio_orb_destroy(ssvio_orb* h)
     if (h->evCand) (void)hipEventDestroy(h->evCand);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
+    if (h->evExp) (void)hipEventDestroy(h->evExp);
+    hfree(h->h_pyrExp);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->own) (void)hipStreamDestroy(h->own);
     delete h;
@@ -758,12 +796,16 @@ int ssvio_orb_extract_batch(ssvio_orb* h, const uint8_t* imgs, int batch, int ch
         SSVIO_HIP(hipHostGetDevicePointer((void**)&h->d_landing, h->h_landing, 0));
         h->landingCap = kpBytes + dBytes;
     }
+    h->exportValid = false;
+    if (h->exportPyr && batch == 1) { rc = orb_ensure_export(h); if (rc) return rc; h->exportNow = true; }
     h->hostKp = (ssvio_keypoint*)h->d_landing; h->hostDesc = h->d_landing + kpBytes;
     rc = orb_run(h, batch, false);
     h->hostKp = nullptr; h->hostDesc = nullptr;
+    const bool exported = h->exportNow; h->exportNow = false;
     if (rc) return rc;
     rc = orb_wait(h);
     if (rc) return rc;
+    h->exportValid = exported;
     for (int f = 0; f < batch; ++f) {
         const int c = h->h_kpCount[f];
         if (c > cap) { set_error("frame %d has %d keypoints, caller capacity is %d", f, c, cap); return SSVIO_ERR_CAPACITY; }
@@ -823,6 +865,25 @@ int ssvio_orb_pyramid_level(ssvio_orb* h, int frame, int level, uint8_t* dst, in
         memcpy(dst + (size_t)(kEdge - i) * dst_stride, dst + (size_t)(kEdge + refl101_host(-i, L.h)) * dst_stride, (size_t)L.w + 2 * kEdge);
         memcpy(dst + (size_t)(kEdge + L.h - 1 + i) * dst_stride, dst + (size_t)(kEdge + refl101_host(L.h - 1 + i, L.h)) * dst_stride, (size_t)L.w + 2 * kEdge);
     }
+    return SSVIO_OK;
+}
+
+int ssvio_orb_set_export_pyramid(ssvio_orb* h, int enable)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    h->exportPyr = enable != 0;
+    if (!h->exportPyr) h->exportValid = false;
+    return SSVIO_OK;
+}
+
+int ssvio_orb_exported_pyramid_level(ssvio_orb* h, int level, const uint8_t** base, int* stride, int* lw, int* lh)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    if (!h->exportValid || !h->haveResults || level < 0 || level >= h->geom.nlevels || !base || !stride) {
+        set_error("no exported pyramid (ssvio_orb_set_export_pyramid + a single-frame ssvio_orb_extract[_rgb] call) or bad level"); return SSVIO_ERR_INVALID;
+    }
+    *base = h->h_pyrExp + h->expLay.offset[level]; *stride = h->expLay.stride[level];
+    if (lw) *lw = h->geom.lv[level].w; if (lh) *lh = h->geom.lv[level].h;
     return SSVIO_OK;
 }
 

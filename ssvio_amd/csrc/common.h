@@ -185,6 +185,9 @@ int  launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipS
 void quadtree_prepare();
 size_t quadtree_lds_bytes(int maxa);   // bytes of node arrays for a capacity of maxa live nodes (LDS or HBM scratch)
 constexpr int kQtMaxLds = 2048, kQtMaxGlobal = 32768;
+// where the rimmed levels of the exported pyramid sit in the mapped host area (byte offsets, row strides: multiples of 64)
+struct ExportLayout { unsigned long long offset[kMaxLevels]; int stride[kMaxLevels]; };
+void launch_export_pyramid(const uint8_t* pyrFrame0, const KLevels& kl, const ExportLayout& lay, int maxRows, uint8_t* dst, hipStream_t s);
 void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl, int stripsPerFrame, int batch, hipStream_t s);
 // sel: per level lists {x | y<<16, level | resp<<8} at f*selPerFrame + selBase[l]; selCount[f][kMaxLevels]
 void launch_describe(const uint8_t* pyr, const uint8_t* blur, size_t pyrFrameBytes, const KLevels& kl,

@@ -762,6 +762,35 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, size_t pyrFrameBytes, const 
 }
 
 // ---------------------------------------------------------------------------
+// mvImagePyramid (public member, include/Feature.h:45; src/Feature.cpp:806-821): every level of frame 0 with its 19-px
+// BORDER_REFLECT_101 rim, written straight into pinned, device-mapped host memory (the adapter's cv::Mat headers point into it).
+// One wave per rimmed row, a dword (4 pixels) per lane and step.
+__global__ __launch_bounds__(256) void k_export_pyramid(const uint8_t* __restrict__ pyr, KLevels kl, ExportLayout lay, uint8_t* __restrict__ dst)
+{
+    const int level = blockIdx.y;
+    const KLevel& L = kl.lv[level];
+    const int w = L.w, h = L.h, stride = lay.stride[level];
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= h + 2 * kEdge) return;                               // wave-uniform
+    const uint8_t* src = pyr + L.offset + (size_t)refl101(y - kEdge, h) * L.pitch;
+    uint32_t* out = (uint32_t*)(dst + lay.offset[level] + (size_t)y * stride);
+    for (int c = threadIdx.x & 63; 4 * c < w + 2 * kEdge; c += 64) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = 4 * c + i - kEdge;
+            if (x < w + kEdge) v |= (uint32_t)src[refl101(x, w)] << (8 * i);
+        }
+        out[c] = v;
+    }
+}
+
+void launch_export_pyramid(const uint8_t* pyrFrame0, const KLevels& kl, const ExportLayout& lay, int maxRows, uint8_t* dst, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_export_pyramid, dim3((maxRows + 3) / 4, kl.nlevels), dim3(256), 0, s, pyrFrame0, kl, lay, dst);
+}
+
+// ---------------------------------------------------------------------------
 // IC_Angle (src/Feature.cpp:84-113) + steered BRIEF (src/Feature.cpp:446-482): one wave per keypoint.
 constexpr int8_t kPatternI8[1024] = {
 #include "orb_pattern.inc"

@@ -126,6 +126,21 @@ class ORBextractor:
         return out
 
     # ---- stage taps (tests)
+    def set_export_pyramid(self, on):
+        """every single-frame Extract / ExtractRGB also stores the rimmed pyramid into pinned host memory (mvImagePyramid, include/Feature.h:45)"""
+        L.check(L.lib().ssvio_orb_set_export_pyramid(self._h, int(on)))
+
+    def exported_pyramid(self):
+        """the rimmed levels of the last single-frame call as copies of the handle's pinned area: (h + 38) x (w + 38) each"""
+        out = []
+        for l in range(self.nlevels):
+            base = C.c_void_p(); stride, w, h = C.c_int(0), C.c_int(0), C.c_int(0)
+            L.check(L.lib().ssvio_orb_exported_pyramid_level(self._h, l, C.byref(base), C.byref(stride), C.byref(w), C.byref(h)))
+            rows = h.value + 38
+            a = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_uint8)), shape=(rows * stride.value,)).reshape(rows, stride.value)
+            out.append(a[:, :w.value + 38].copy())
+        return out
+
     def debug_level_image(self, level, blurred=False, frame=0):
         g = self.level_geometry(self._last[1], self._last[2], level)
         buf = np.zeros((g["h"], g["w"]), np.uint8)

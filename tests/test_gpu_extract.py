@@ -206,6 +206,35 @@ def test_mvImagePyramid_has_reflect101_rim(mods):
     g.close()
 
 
+@pytest.mark.parametrize("shape", [(240, 320), (480, 640), (231, 333)])
+def test_exported_pyramid_equals_the_fetched_one(mods, shape):
+    """ssvio_orb_set_export_pyramid: the rimmed levels a kernel stores into pinned host memory during the call (what the C++ adapter
+    points mvImagePyramid at) against the oracle's levels with their BORDER_REFLECT_101 rim; results of the call unchanged"""
+    S, synth, O = mods
+    img = synth.texture(19, *shape)
+    g = S.ORBextractor(500, 1.2, 8, 20, 7); c = O.Extractor(500, 1.2, 8, 20, 7)
+    k0, d0 = g.Extract(img)
+    with pytest.raises(S.SsvioError):
+        g.exported_pyramid()                                        # not enabled yet
+    g.set_export_pyramid(True)
+    for rgb in (False, True):
+        k1, d1 = g.ExtractRGB(synth.to_rgb(img, 1)) if rgb else g.Extract(img)
+        src = img
+        if rgb:
+            c.extract_rgb(synth.to_rgb(img, 1))
+        else:
+            c.extract(src)
+            assert np.array_equal(k1.view(np.uint8), k0.view(np.uint8)) and np.array_equal(d1, d0)
+        pyr = g.exported_pyramid()
+        for l in range(8):
+            assert np.array_equal(pyr[l], O.border_reflect101(c.level_image(l), 19)), (rgb, l)
+    g.set_export_pyramid(False)
+    g.Extract(img)
+    with pytest.raises(S.SsvioError):
+        g.exported_pyramid()
+    g.close()
+
+
 def test_1080p_4000_features(mods):
     S, synth, O = mods
     img = synth.texture(101, 1080, 1920)
