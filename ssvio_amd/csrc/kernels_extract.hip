@@ -405,11 +405,16 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
 {
     constexpr int kFtRows = FH + 8, kScRows = FH + 2;
     constexpr int kLoadPasses = (kFtRows + 13) / 14, kScanPasses = (kScRows + 13) / 14;      // rows r0, r0+14, ... per thread
+    // rows of the half-value tile that phase 1 may address: score row r0 + 14 k (r0 <= 13) reads input rows r .. r + 6; never fewer than
+    // the two phase-2/3 queues need, which live in the same memory once phase 1 is over
+    constexpr int kHalfRows = 14 * (kScanPasses - 1) + 20 > 57 ? 14 * (kScanPasses - 1) + 20 : 57;
     __shared__ __attribute__((aligned(16))) uint32_t tile[kFtRows * kFtPitch / 4];
     __shared__ __attribute__((aligned(16))) uint32_t sc[kScRows * kFtPitch / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t half[kHalfRows * kFtPitch / 4];     // (pixel >> 1) & 0x7f, phase 1's operands
     __shared__ uint16_t queue[kFtQueueCap];              // pixels that pass the compass test (positions in the score tile)
-    __shared__ uint16_t cqueue[kFtCornerCap];            // ... of those, the corners (score >= the lower threshold): the NMS walks only these
-    __shared__ uint2 outbuf[kFtOutCap];                  // NMS survivors of one tile (beyond the capacity they are appended one by one)
+    static_assert(sizeof(half) >= kFtCornerCap * sizeof(uint16_t) + kFtOutCap * sizeof(uint2), "the queues of phases 2 and 3 reuse the half-value tile");
+    uint16_t* const cqueue = (uint16_t*)half;            // ... of those, the corners (score >= the lower threshold): the NMS walks only these
+    uint2* const outbuf = (uint2*)(half + kFtCornerCap / 2);      // NMS survivors of one tile (beyond the capacity they are appended one by one)
     __shared__ int qn, cn, on, obase;
     const int tid = threadIdx.x;
     int frame, tileId;
@@ -428,6 +433,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     // thread -> (row r0 = tid / 18, dword column c = tid % 18) once; rows r0, r0+14, r0+28, ... per pass (252 threads busy)
     const int r0 = (int)(__umul24(tid, 3641u) >> 16), c0 = tid - r0 * (kFtPitch / 4);
     const bool lane252 = tid < 252;
+    constexpr uint32_t H = 0x80808080u, M7 = 0x7f7f7f7fu;
     {
         uint32_t ld[kLoadPasses];
         const int xoff = min(x0 - 4 + 4 * c0, xMaxLoad);
@@ -435,12 +441,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
         for (int k = 0; k < kLoadPasses; ++k) {
             const int r = r0 + 14 * k;
             const int yy = min(max(y0 - 4 + r, 0), h - 1);
-            ld[k] = (lane252 && r < ftRows) ? *(const uint32_t*)(img + (size_t)yy * pitch + xoff) : 0u;
+            // a level is far below 4 GB: 32-bit lane offsets from the wave-uniform base
+            ld[k] = (lane252 && r < ftRows) ? *(const uint32_t*)(img + ((uint32_t)yy * (uint32_t)pitch + (uint32_t)xoff)) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < kLoadPasses; ++k) {
             const int r = r0 + 14 * k;
-            if (lane252 && r < ftRows) tile[r * (kFtPitch / 4) + c0] = ld[k];
+            if (lane252 && r < ftRows) { tile[r * (kFtPitch / 4) + c0] = ld[k]; half[r * (kFtPitch / 4) + c0] = (ld[k] >> 1) & M7; }
             if (lane252 && r < scRows) sc[r * (kFtPitch / 4) + c0] = 0;
         }
     }
@@ -457,35 +464,42 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     // 3 % more pixels pass than with the full 8 bits (measured on the bench's frames); none fewer.
     // Domain: score rows y0-1 .. y0+th (r = 0..th+1), quad columns x0-4 .. x0+67 (pixels outside cLo .. cHi dropped).
     unsigned flagsD = 0, flagsB = 0;                        // bit (8i+k): pixel i of this thread's quad of pass k survives the darker / brighter test (kScanPasses <= 5)
-    constexpr uint32_t H = 0x80808080u, M7 = 0x7f7f7f7fu;
     const uint32_t tq = (uint32_t)min((tLow + 1) >> 1, 128) * 0x01010101u;
     const int qc = c0;
     // One flag byte (0x80) per pixel.  A thread's four columns are the same in every pass: their mask is built once.
     uint32_t colMask = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (lane252 && 4 * qc + i >= cLo && 4 * qc + i <= cHi) colMask |= 0x80u << (8 * i);
+    // ... and so are its rows r0 + 14 k: score row r is tested iff r < scRows and kEdge <= y0 - 1 + r <= h - kEdge - 1, i.e. the passes
+    // k < ceil((lim - r0) / 14), less pass 0 for the first score row of the level's first tile row.  Untested rows are scanned like the
+    // others (whatever the half-value tile holds there) and dropped from the flags afterwards.
+    const int lim = min(scRows, h - kEdge - y0 + 1) - r0;
+    uint32_t rowBits = (1u << (lim > 0 ? min((int)(__umul24((uint32_t)(lim + 13), 4682u) >> 16), kScanPasses) : 0)) - 1u;     // x / 14 for x < 4096
+    if (y0 - 1 + r0 < kEdge) rowBits &= ~1u;
+    rowBits *= 0x01010101u;
+    // the operands are the pixels' upper 7 bits (written beside the tile at load time); every pass is a fixed offset from these three
+    const uint32_t* hC = half + ((lane252 ? r0 : 0) + 3) * (kFtPitch / 4) + qc;
+    const uint32_t* hL = hC - (qc > 0 ? 1 : 0);
+    const uint32_t* hR = hC + (qc < 17 ? 1 : 0);
 #pragma unroll
     for (int k = 0; k < kScanPasses; ++k) {
         if (14 * k >= scRows) break;                        // block-uniform: short tiles need fewer passes
-        const int r = min(r0 + 14 * k, kScRows - 1);
-        const int y = y0 - 1 + r;
-        const bool rowOk = r0 + 14 * k < scRows && y >= kEdge && y <= h - kEdge - 1;      // a tested row of this tile's score domain
-        const int rowC = (r + 3) * (kFtPitch / 4);          // input row of score row r
-        const uint32_t C = tile[rowC + qc], Lf = tile[rowC + max(qc - 1, 0)], Rt = tile[rowC + min(qc + 1, 17)];
-        const uint32_t U = tile[rowC - 3 * (kFtPitch / 4) + qc], D = tile[rowC + 3 * (kFtPitch / 4) + qc];
-        const uint32_t lw = __builtin_amdgcn_alignbyte(C, Lf, 1);     // bytes x-3 .. x
-        const uint32_t rw = __builtin_amdgcn_alignbyte(Rt, C, 3);     // bytes x+3 .. x+6
-        const uint32_t c = (C >> 1) & M7, u = (U >> 1) & M7, d = (D >> 1) & M7, l = (lw >> 1) & M7, rr = (rw >> 1) & M7;
+        constexpr int kRow = kFtPitch / 4;
+        const int o = 14 * k * kRow;                        // score row r0 + 14 k <-> input row r + 3
+        const uint32_t c = hC[o], Lf = hL[o], Rt = hR[o], u = hC[o - 3 * kRow], d = hC[o + 3 * kRow];
+        const uint32_t l = __builtin_amdgcn_alignbyte(c, Lf, 1);      // bytes x-3 .. x
+        const uint32_t rr = __builtin_amdgcn_alignbyte(Rt, c, 3);     // bytes x+3 .. x+6
         // darker: c - t >= X on one vertical AND one horizontal compass pixel (bit 7 of P: c >= t at all)
         const uint32_t P = (c | H) - tq, Ad = P | H;
         const uint32_t dk = (((Ad - u) | (Ad - d)) & ((Ad - l) | (Ad - rr))) & P;
         // brighter: X >= c + t (bit 7 of Q: c + t is beyond any 7-bit value)
         const uint32_t Q = c + tq, Bq = Q & M7;
         const uint32_t br = ((((u | H) - Bq) | ((d | H) - Bq)) & (((l | H) - Bq) | ((rr | H) - Bq))) & (Q ^ H);
-        const uint32_t okMask = rowOk ? colMask : 0u;
-        flagsD |= (dk & okMask) >> (7 - k);
-        flagsB |= (br & okMask) >> (7 - k);
+        flagsD |= (dk & colMask) >> (7 - k);
+        flagsB |= (br & colMask) >> (7 - k);
     }
+    flagsD &= rowBits;
+    flagsB &= rowBits;
     {   // one queue reservation per wave
         const int lane = tid & 63;
         const int cnt = __popc(flagsD) + __popc(flagsB);
