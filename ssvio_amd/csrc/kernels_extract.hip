@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     __shared__ __attribute__((aligned(16))) uint32_t tile[kFtRows * kFtPitch / 4];
     __shared__ __attribute__((aligned(16))) uint32_t sc[kScRows * kFtPitch / 4];
     __shared__ __attribute__((aligned(16))) uint32_t half[kHalfRows * kFtPitch / 4];     // (pixel >> 1) & 0x7f, phase 1's operands
-    __shared__ uint16_t queue[kFtQueueCap];              // pixels that pass the compass test (positions in the score tile)
+    __shared__ uint16_t queue[kFtQueueCap + 2];          // pixels that pass the compass test (+ a spare slot that takes what overflows)
     static_assert(sizeof(half) >= kFtCornerCap * sizeof(uint16_t) + kFtOutCap * sizeof(uint2), "the queues of phases 2 and 3 reuse the half-value tile");
     uint16_t* const cqueue = (uint16_t*)half;            // ... of those, the corners (score >= the lower threshold): the NMS walks only these
     uint2* const outbuf = (uint2*)(half + kFtCornerCap / 2);      // NMS survivors of one tile (beyond the capacity they are appended one by one)
@@ -516,19 +516,15 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
             int base = 0;
             if (lane == 63) base = atomicAdd(&qn, tot);
             base = __builtin_amdgcn_readlane(base, 63) + incl - cnt;
-            const int e0 = r0 * kFtPitch + 4 * qc;              // byte index of this thread's first quad in the score tile
-            // an entry = position | polarity << 15 (a pixel that passes both tests is queued twice; at most one of the two is a corner)
-            unsigned f = flagsD;
-            while (f) {
-                const int bit = __ffs(f) - 1; f &= f - 1;
-                if (base < kFtQueueCap) queue[base] = (uint16_t)(e0 + (bit & 7) * (14 * kFtPitch) + (bit >> 3));
-                ++base;
-            }
-            f = flagsB;
-            while (f) {
-                const int bit = __ffs(f) - 1; f &= f - 1;
-                if (base < kFtQueueCap) queue[base] = (uint16_t)((e0 + (bit & 7) * (14 * kFtPitch) + (bit >> 3)) | 0x8000);
-                ++base;
+            // an entry = thread << 5 | flag bit (8 i + k), bit 13 = the brighter test (a pixel that passes both tests is queued twice; at
+            // most one of the two is a corner); phase 2 turns it into the pixel's position, once per entry instead of inside this
+            // divergent loop.  One darker and one brighter entry per round; entries beyond the capacity land on the spare slot.
+            unsigned f = flagsD, g = flagsB;
+            const unsigned eD = (unsigned)tid << 5, eB = eD | 0x2000u;
+            int iD = base, iB = base + __popc(flagsD);
+            while (f | g) {
+                if (f) { queue[min(iD, kFtQueueCap)] = (uint16_t)(eD + (unsigned)(__ffs(f) - 1)); f &= f - 1; ++iD; }
+                if (g) { queue[min(iB, kFtQueueCap)] = (uint16_t)(eB + (unsigned)(__ffs(g) - 1)); g &= g - 1; ++iB; }
             }
         }
     }
@@ -565,7 +561,12 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
         for (int q0 = 0; q0 < nq; q0 += 256) {                  // waves whose 64 entries lie beyond nq skip the body
             const int q = q0 + tid;
             int p = 0; bool corner = false;
-            if (q < nq) { const int e = queue[q]; p = e & 0x7FFF; corner = score(p, e >> 15); }
+            if (q < nq) {
+                const int e = queue[q], t = (e >> 5) & 255, bit = e & 31;
+                const int tr = (int)(__umul24((uint32_t)t, 3641u) >> 16), tc = t - tr * (kFtPitch / 4);
+                p = tr * kFtPitch + 4 * tc + (bit & 7) * (14 * kFtPitch) + (bit >> 3);      // position in the score tile
+                corner = score(p, e >> 13);
+            }
             push_corner(corner, p);
         }
     } else {
