@@ -172,8 +172,10 @@ __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, 
     const ResizeQuad e = qtab[live ? qi : 0];
     const uint32_t b = e.bOff & 0xFFFFFF, off = e.bOff >> 24;
     const uint8_t* S = pyr + (size_t)frame * pyrFrameBytes + srcOff;
-    uint8_t* D = pyr + (size_t)frame * pyrFrameBytes + dstOff + 4 * qi - kPadX;
-    const int sBeg = ytab[yBeg].x, sEnd = ytab[yEnd - 1].y;                   // wave-uniform
+    uint8_t* D = pyr + (size_t)frame * pyrFrameBytes + dstOff;               // wave-uniform; the lane's quad starts 4 qi - kPadX into a row
+    const uint32_t dq = 4u * (uint32_t)qi;                                   // ... taken from D - kPadX, so that the offsets stay unsigned
+    // wave-uniform, and told so: 16-bit loads come back in VGPRs, and with them the row addresses below would be 64-bit VALU arithmetic
+    const int sBeg = __builtin_amdgcn_readfirstlane(ytab[yBeg].x), sEnd = __builtin_amdgcn_readfirstlane(ytab[yEnd - 1].y);
     // per pixel of the quad: the selector that lays its taps out as (tap0, 0, tap1, 0) and its coefficients (0 .. 2048) as a u16 pair
     uint32_t selp[4]; ushort2v wa[4];
 #pragma unroll
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, 
     uint32_t A[kResizeSrcRows], B[kResizeSrcRows], C[kResizeSrcRows];
 #pragma unroll
     for (int j = 0; j < kResizeSrcRows; ++j) {
-        const uint32_t* r = (const uint32_t*)(S + (size_t)min(sBeg + j, sEnd) * srcPitch) + b;
+        // scalar base, 32-bit lane offset (a level is far below 4 GB): one add per row instead of a 64-bit multiply-add
+        const uint32_t* r = (const uint32_t*)(S + ((uint32_t)(min(sBeg + j, sEnd) * srcPitch) + 4u * b));
         A[j] = r[0]; B[j] = r[1]; C[j] = r[2];
     }
     int y = yBeg;                                        // next output row to finish (uniform)
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, 
                 const int r = (((ty.z * t0) >> 16) + ((ty.w * Tc[i]) >> 16) + 2) >> 2;
                 v |= (uint32_t)(r & 255) << (8 * i);
             }
-            if (live) *(uint32_t*)(D + (size_t)y * dstPitch) = v;
+            if (live) *(uint32_t*)((D - kPadX) + ((uint32_t)(y * dstPitch) + dq)) = v;
             ++y;
             ty = ytab[min(y, dh - 1)];
         }
