@@ -299,6 +299,9 @@ static int orb_ensure(ssvio_orb* h, int width, int height, int batch, size_t inB
         SSVIO_HIP(hipMalloc(&h->d_kord, B * g.slotsPerFrame * sizeof(uint32_t)));
         SSVIO_HIP(hipMalloc(&h->d_knode, B * g.slotsPerFrame * sizeof(uint32_t)));
         SSVIO_HIP(hipMalloc(&h->d_sel, B * h->kpCap * sizeof(uint2)));
+        // k_describe fetches a slot's patches before it knows whether the slot is in use: every slot holds a position that is valid
+        // in every level from the start (the quadtree only ever overwrites a slot with a keypoint of the slot's own level)
+        SSVIO_HIP(hipMemsetD32Async((hipDeviceptr_t)h->d_sel, (int)((unsigned)kEdge | ((unsigned)kEdge << 16)), B * h->kpCap * 2, h->stream));
         SSVIO_HIP(hipMalloc(&h->d_selCount, B * kMaxLevels * sizeof(int)));
         SSVIO_HIP(hipMalloc(&h->d_kpCount, B * sizeof(int)));
         SSVIO_HIP(hipMalloc(&h->d_kpOut, B * h->kpCap * sizeof(ssvio_keypoint)));
@@ -362,7 +365,7 @@ static int orb_host_quadtree(ssvio_orb* h, int batch)
     const int L = g.nlevels;
     int rc = orb_fetch_raw(h, batch);
     if (rc) return rc;
-    h->h_sel.assign((size_t)batch * h->kpCap, make_uint2(0, 0));
+    h->h_sel.assign((size_t)batch * h->kpCap, make_uint2((unsigned)kEdge | ((unsigned)kEdge << 16), 0));     // unused slots: a valid position (k_describe)
     h->h_selCount.assign((size_t)batch * kMaxLevels, 0);
     std::atomic<int> fail{0};
     auto job = [&](int j) {

@@ -934,37 +934,28 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
     int frame, blk;
     xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
     const int lane = threadIdx.x & 63, sl = lane & 31, half = lane >> 5;
-    const int k = (blk * (kDescThreads / 64) + (threadIdx.x >> 6)) * 2 + half;
-    // the 4-KB test pattern is fetched once per workgroup; every wave then reads its records from LDS
-    __shared__ float4 spat[256];
-    if (threadIdx.x < 256) spat[threadIdx.x] = ((const float4*)c_patf.v)[threadIdx.x];
-    __syncthreads();
-    // keypoint k of the frame in level-major order (src/Feature.cpp:537-567): locate its level list.  Lane l < 16 of each
-    // half holds the inclusive prefix of the level counts; the level is the number of prefixes <= k.
-    int level, before, total;
-    {
-        const int l = sl & 15;
-        int incl = l < kl.nlevels ? selCount[frame * kMaxLevels + l] : 0;
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);      // row_shr 1, 2, 4, 8: inclusive scan inside each row of 16
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
-        total = __builtin_amdgcn_readlane(incl, 15);
-        const unsigned long long vote = __ballot(sl < kl.nlevels && incl <= k);
-        level = __popc(half ? (uint32_t)(vote >> 32) : (uint32_t)vote);
-        before = __shfl(incl, max(level - 1, 0), 16);                 // lanes 0..15 of the same half
-        if (level == 0) before = 0;
-    }
-    if (blk == 0 && threadIdx.x == 0) { kpCount[frame] = total; kpCountHost[frame] = total; }   // second copy lands in pinned host memory
-    if (__builtin_amdgcn_readfirstlane(k) >= total) return;        // the lower half's keypoint is the smaller index
-    const bool live = k < total;
-    if (!live) level = 0;
+    // A half-wave takes one SLOT of the frame's selected-keypoint list, not the k-th keypoint: the slot's level is known from the
+    // host-built level bases alone, so the record can be fetched at once and the patch loads behind it -- two dependent memory round
+    // trips per wave instead of three (the level counts are only needed for where the results go, and travel beside the record).
+    // Slots beyond a level's count hold a valid position of that level (the list is initialised to (kEdge, kEdge) when it is
+    // allocated and only ever overwritten by the quadtree with keypoints of the same level), so their loads are harmless; they are
+    // dropped once the counts are in.
+    const int slotRaw = (blk * (kDescThreads / 64) + (threadIdx.x >> 6)) * 2 + half;
+    const bool inList = slotRaw < selPerFrame;                    // the grid is rounded up to whole workgroups
+    const int slot = inList ? slotRaw : 0;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; ++l) level += (l < kl.nlevels && slot >= kl.lv[l].selBase) ? 1 : 0;
     const KLevel& L = kl.lv[level];
-    int x = kEdge, y = kEdge, resp = 0;
-    if (live) {
-        const uint2 in = sel[(size_t)frame * selPerFrame + L.selBase + (k - before)];
-        x = in.x & 0xFFFF; y = in.x >> 16; resp = (in.y >> 8) & 0xFF;
-    }
+    const int idx = slot - L.selBase;                             // position in the level's list
+    const uint2 in = sel[(size_t)frame * selPerFrame + slot];
+    // the level counts of the frame: lane l < 16 of each half holds the inclusive prefix (consumed below, after the patch loads are out)
+    int incl = (sl & 15) < kl.nlevels ? selCount[frame * kMaxLevels + (sl & 15)] : 0;
+    // the 4-KB test pattern goes to LDS once per workgroup; its load travels with the others, its barrier comes after them
+    __shared__ float4 spat[256];
+    float4 patv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < 256) patv = ((const float4*)c_patf.v)[threadIdx.x];
+    const int x = in.x & 0xFFFF, y = in.x >> 16, resp = (in.y >> 8) & 0xFF;
     const int pitch = L.pitch;
     const uint8_t* pyrF = pyr + (size_t)frame * pyrFrameBytes;           // wave-uniform bases, 32-bit lane offsets
     const uint8_t* blurF = blur + (size_t)frame * pyrFrameBytes;
@@ -994,6 +985,24 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
 #pragma unroll
         for (int t = 0; t < 13; ++t) { wb[t] = *(const uint32_t*)(blurF + o); o += step3; }
     }
+    if (threadIdx.x < 256) spat[threadIdx.x] = patv;
+    __syncthreads();
+    // keypoints come out in level-major order (src/Feature.cpp:537-567): this slot's keypoint is number before + idx of the frame
+    int total, before;
+    {
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);      // row_shr 1, 2, 4, 8: inclusive scan inside each row of 16
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+        total = __builtin_amdgcn_readlane(incl, 15);
+        before = __shfl(incl, max(level - 1, 0), 16);                 // lanes 0..15 of the same half
+        if (level == 0) before = 0;
+    }
+    const int count = __shfl(incl, level, 16) - before;               // this level's count
+    if (blk == 0 && threadIdx.x == 0) { kpCount[frame] = total; kpCountHost[frame] = total; }   // second copy lands in pinned host memory
+    const bool live = inList && idx < count;
+    if (!__any(live)) return;
+    const int k = before + idx;
 #pragma unroll
     for (int t = 0; t < 10; ++t) if (sl < 27 && (t < 9 || ri < 2)) lp[sl + 27 * t] = wi[t];
     int m01 = 0, m10 = 0;

@@ -7,7 +7,7 @@ for i in 1 2 3; do
     python3 - $v <<'PY'
 import json,sys
 d=json.loads(open('gpurun_out/tmp_b.json').read().strip().splitlines()[-1])
-print(sys.argv[1], 'value', d['value'], 'sustained', d['sustained']['value'], 'k_fast excl', d["kernels"]["k_fast"]["avg_us"], "blur", d["kernels"]["k_blur"]["avg_us"], "describe", d["kernels"]["k_describe"]["avg_us"], "cfg0", d["configs"][0]["value"], 'level0', d['kernels']['k_copy_gray']['avg_us'], 'in-region', d['roofline']['avg_launch_us'])
+print(sys.argv[1], 'value', d['value'], 'sustained', d['sustained']['value'], 'k_fast excl', d["kernels"]["k_fast"]["avg_us"], "blur", d["kernels"]["k_blur"]["avg_us"], "describe", d["kernels"]["k_describe"]["avg_us"], "resize", d["kernels"]["k_resize"]["avg_us"], "knn2", d["kernels"]["k_hamming_knn2"]["avg_us"], "qt", d["kernels"]["k_quadtree"]["avg_us"], "cfg0", d["configs"][0]["value"], 'level0', d['kernels']['k_copy_gray']['avg_us'], 'in-region', d['roofline']['avg_launch_us'])
 PY
   done
 done
