@@ -195,6 +195,37 @@ def test_flat_and_empty_inputs(mods):
     g.close()
 
 
+def test_unused_slots_of_the_keypoint_list_never_leak(mods):
+    """k_describe takes slots of the per-level selected-keypoint list and fetches their patches before the level counts are in;
+    slots beyond a level's count keep whatever an earlier, denser frame left there.  One handle: dense, sparse, flat, sparse batch
+    with mixed frames, dense again -- every result against the oracle."""
+    S, synth, O = mods
+    h, w = 480, 640
+    dense = synth.texture(3, h, w)
+    sparse = np.full((h, w), 90, np.uint8)
+    rng = np.random.default_rng(5)
+    for _ in range(40):                                            # a few dozen isolated blobs: most levels stay far below their quota
+        y, x = int(rng.integers(40, h - 48)), int(rng.integers(40, w - 48))
+        sparse[y:y + 7, x:x + 9] = int(rng.integers(150, 255))
+    flat = np.full((h, w), 31, np.uint8)
+    g = S.ORBextractor(1000, 1.2, 8, 20, 7); c = O.Extractor(1000, 1.2, 8, 20, 7)
+    n_dense = None
+    for img in (dense, sparse, flat, sparse, dense):
+        kps, desc = g.Extract(img)
+        rk, _ = _cmp_frame(O, g, c, img, kps, desc)
+        if n_dense is None: n_dense = len(rk)
+    assert n_dense > 900
+    frames = np.stack([dense, sparse, flat, sparse, dense, flat])
+    kps, desc, n = g.extract_batch(frames)
+    for f in range(len(frames)):
+        rk, rd = c.extract(frames[f])
+        assert n[f] == len(rk), "frame %d" % f
+        assert np.array_equal(kps[f, :n[f]].view(np.uint8), rk.view(np.uint8)), "frame %d keypoints" % f
+        assert np.array_equal(desc[f, :n[f]], rd), "frame %d descriptors" % f
+    assert 0 < n[1] < 700 and n[2] == 0
+    g.close()
+
+
 def test_mvImagePyramid_has_reflect101_rim(mods):
     S, synth, O = mods
     img = synth.texture(9, 240, 320)
