@@ -415,13 +415,14 @@ def extra_configs(dev, frames_vga, with_cpu=True):
                                     "what": "ORBextractor.Extract + MatchByBruteForce on pageable host arrays (PCIe inclusive, python wrappers)"}})
 
     # ---- configs[1] streamed: 256 distinct frames in pinned host memory, H2D copies on a copy stream, double-buffered against compute
-    B, S, nfr = int(os.environ.get("SSVIO_BENCH_STREAMED_BATCH", "128")), int(os.environ.get("SSVIO_BENCH_STREAMED_IN_FLIGHT", "3")), 256
+    # (round 3, batch / in flight / spare buffers: 128/3/1 155.7 k, 128/3/3 154.9 k, 256/3/3 158.9 k, 128/4/4 132.1 k, 256/4/2 139.3 k, 128/6/6 150.3 k frames/s -- the copy stream wants a hardware queue of its own)
+    B, S, nfr = int(os.environ.get("SSVIO_BENCH_STREAMED_BATCH", "256")), int(os.environ.get("SSVIO_BENCH_STREAMED_IN_FLIGHT", "3")), 512
     frames = synth.frame_stream(2000, nfr, H, W)
     pinned = torch.from_numpy(frames).pin_memory()
     p = Pipeline(dev, 1000, S, torch_streams=True)
     ncopy = int(os.environ.get("SSVIO_BENCH_COPY_STREAMS", "1"))      # a batch goes up in ncopy slices, one copy stream each (measured: 1 -> 122 k, 2 -> 82 k, 4 -> 65 k frames/s: more streams crowd the 4 hardware queues)
     copy_sts = [torch.cuda.Stream(device=dev) for _ in range(ncopy)]
-    nbuf = S + int(os.environ.get("SSVIO_BENCH_STREAMED_SPARE_BUFFERS", "1"))
+    nbuf = S + int(os.environ.get("SSVIO_BENCH_STREAMED_SPARE_BUFFERS", "3"))
     d_in = [torch.empty((B, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     ready = [[torch.cuda.Event() for _ in range(ncopy)] for _ in range(nbuf)]; free = [torch.cuda.Event() for _ in range(nbuf)]
     used = [False] * nbuf
@@ -446,7 +447,7 @@ def extra_configs(dev, frames_vga, with_cpu=True):
     for _ in range(8):
         sstep()
     p.sync(); torch.cuda.synchronize()
-    ns = 120
+    ns = 60 if B >= 256 else 120
     t0 = time.perf_counter()
     for _ in range(ns):
         sstep()

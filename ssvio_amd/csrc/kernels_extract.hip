@@ -83,12 +83,62 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ src,
     }
 }
 
+// The common case of level 0 -- 8-bit gray frames whose rows, strides and pyramid slot are all 16-byte aligned -- as a plain block copy:
+// a workgroup takes 16 rows and deals their 16-byte chunks over its 256 threads (a VGA row is only 40 chunks: a wave per row, as in
+// k_level0, leaves 24 lanes idle and spends its instructions on set-up), every thread with two or three independent loads in flight,
+// all addresses 32-bit offsets from two wave-uniform bases.  The pad quads and the tail of a row behind its last whole chunk are
+// gathered byte-wise by the first threads, one quad each.
+constexpr int kL0Rows = 16;
+__global__ __launch_bounds__(256) void k_level0_rows(const uint8_t* __restrict__ src, int w, int h, int stride, size_t frameStride,
+                                                     uint8_t* __restrict__ pyr, size_t pyrFrameBytes, int pitch0, unsigned nvMagic,
+                                                     int* __restrict__ zeroA, int nA, int* __restrict__ zeroB, int nB,
+                                                     int blocksPerFrame, int batch)
+{
+    int frame, blk;
+    xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
+    {   // first kernel of the pipeline: it also clears the FAST stage's counters (no separate memset launches)
+        const unsigned nthreads = gridDim.x * 256u;
+        const unsigned flat = blockIdx.x * 256u + threadIdx.x;
+        for (unsigned i = flat; i < (unsigned)nA; i += nthreads) zeroA[i] = 0;
+        for (unsigned i = flat; i < (unsigned)nB; i += nthreads) zeroB[i] = 0;
+    }
+    const int y0 = blk * kL0Rows;
+    const int nrows = min(kL0Rows, h - y0);
+    const uint8_t* s = src + (size_t)frame * frameStride + (size_t)y0 * stride;          // wave-uniform
+    uint8_t* d = pyr + (size_t)frame * pyrFrameBytes + (size_t)y0 * pitch0;              // pixel 0 of row y0
+    const unsigned nv = (unsigned)w >> 4, total = (unsigned)nrows * nv;
+    for (unsigned c = threadIdx.x; c < total; c += 256u) {
+        const unsigned r = (unsigned)(((unsigned long long)c * nvMagic) >> 22), col = c - r * nv;      // c / nv, exact for c < 16 * 4128 / 16 (host-built magic)
+        *(uint4*)(d + (r * (unsigned)pitch0 + 16u * col)) = *(const uint4*)(s + (r * (unsigned)stride + 16u * col));
+    }
+    const int nq = (w + 2 * kPadX + 3) >> 2;                  // quads of a padded row; quad q covers x = 4 q - kPadX ..
+    const int extra = nq - 4 * (int)nv;                       // quad 0 (left pad) + the quads behind the last whole chunk (<= 8)
+    const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
+    if (r < nrows && j < extra) {
+        const int q = j == 0 ? 0 : 4 * (int)nv + j;
+        const int x0 = 4 * q - kPadX;
+        const uint8_t* sr = s + (unsigned)r * (unsigned)stride;
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v |= (uint32_t)sr[refl_clamp(x0 + i, w)] << (8 * i);
+        *(uint32_t*)(d - kPadX + ((unsigned)r * (unsigned)pitch0 + 4u * (unsigned)q)) = v;
+    }
+}
+
 void launch_copy_gray(const uint8_t* src, int w, int h, int stride, size_t frameStride, int batch,
                       uint8_t* pyr, size_t pyrFrameBytes, int pitch0, int* zeroA, int nA, int* zeroB, int nB, hipStream_t s)
 {
     const int bpf = (h + 3) / 4;
     int aligned4 = ((uintptr_t)src % 4 == 0) && (stride % 4 == 0) && (frameStride % 4 == 0);             // bit 0: dword rows, bit 1: 16-byte rows
     if (((uintptr_t)src % 16 == 0) && (stride % 16 == 0) && (frameStride % 16 == 0) && (pitch0 % 16 == 0) && (pyrFrameBytes % 16 == 0) && ((uintptr_t)pyr % 16 == 0) && w >= 16) aligned4 |= 2;
+    static const bool noRows = getenv("SSVIO_LEVEL0_WAVE_ROWS") != nullptr;       // the one form of rounds 1-2, kept for A/B runs
+    if ((aligned4 & 2) && !noRows) {
+        const int nv = w >> 4, bpfR = (h + kL0Rows - 1) / kL0Rows;
+        const unsigned magic = (unsigned)(((1ull << 22) + nv - 1) / nv);
+        hipLaunchKernelGGL(k_level0_rows, dim3(bpfR * batch), dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, magic, zeroA, nA, zeroB, nB,
+                           bpfR, batch);
+        return;
+    }
     hipLaunchKernelGGL(k_level0<1>, dim3(bpf * batch), dim3(256), 0, s, src, w, h, stride, frameStride, pyr, pyrFrameBytes, pitch0, aligned4, zeroA, nA, zeroB, nB,
                        bpf, batch);
 }
