@@ -121,7 +121,7 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
     const bool needSecond = mode == SSVIO_MODE_KNN2_RATIO || mode == 3;
     if (mode != SSVIO_MODE_CROSSCHECK_CV) {
         ProfScope ps(prof, "k_hamming_knn2", s);
-        if (p.small) launch_knn2_small(a, maxQ, npairs, s); else if (p.mfma) launch_knn2_mfma(a, maxQ, p.qBlocks, npairs, needSecond, s); else launch_knn2(a, maxQ, p.qBlocks, npairs, s);
+        if (p.small) launch_knn2_small(a, maxQ, npairs, needSecond, s); else if (p.mfma) launch_knn2_mfma(a, maxQ, p.qBlocks, npairs, needSecond, s); else launch_knn2(a, maxQ, p.qBlocks, npairs, needSecond, s);
         SSVIO_HIP(hipGetLastError());
     }
     FinalizeArgs f{};
@@ -137,7 +137,7 @@ int match_launch(ssvio_matcher* m, const MatchPlan& p, const uint8_t* d_qdesc, i
         r.nChunks = p.nChunksR; r.chunkRows = p.chunkRowsR; r.partial = partialRev;
         {
             ProfScope ps(prof, "k_hamming_knn2", s);
-            if (p.smallRev) launch_knn2_small(r, maxT, npairs, s); else if (p.mfma) launch_knn2_mfma(r, maxT, p.qBlocksR, npairs, false, s); else launch_knn2(r, maxT, p.qBlocksR, npairs, s);
+            if (p.smallRev) launch_knn2_small(r, maxT, npairs, false, s); else if (p.mfma) launch_knn2_mfma(r, maxT, p.qBlocksR, npairs, false, s); else launch_knn2(r, maxT, p.qBlocksR, npairs, false, s);
             SSVIO_HIP(hipGetLastError());
         }
         f.partialRev = partialRev; f.nChunksRev = p.nChunksR;

@@ -30,7 +30,8 @@ __device__ __forceinline__ uint32_t bcnt0(uint32_t x)
 }
 
 // one train row against the lane's R queries: ComputeMatchingScore + the best/second-best update
-template <int R>
+// SECOND = false (MatchByBruteForce and the cross-checks never read the second key): one instruction less per pair
+template <int R, bool SECOND = true>
 __device__ __forceinline__ void row_update(const uint32_t (&q)[R][8], uint32_t (&k1)[R], uint32_t (&k2)[R],
                                            const uint4 lo, const uint4 hi, const uint32_t idx)
 {
@@ -51,12 +52,12 @@ __device__ __forceinline__ void row_update(const uint32_t (&q)[R][8], uint32_t (
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t key = (d[r] << 23) | idx;
-        k2[r] = umed3(k1[r], k2[r], key);     // second smallest of {k1,k2,key}, k1 <= k2
+        if (SECOND) k2[r] = umed3(k1[r], k2[r], key);     // second smallest of {k1,k2,key}, k1 <= k2
         k1[r] = min(k1[r], key);
     }
 }
 
-template <int R>
+template <int R, bool SECOND>
 __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
 {
     __shared__ uint4 tile[2][kTT * 2 + 2];            // two buffers: the next tile lands while this one is consumed (+ a row of slack: the row prefetch)
@@ -106,13 +107,13 @@ __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint4 nlo = tl[2 * (j + u) + 2], nhi = tl[2 * (j + u) + 3];
-                    row_update<R>(q, k1, k2, lo, hi, (uint32_t)(t0 + j + u));
+                    row_update<R, SECOND>(q, k1, k2, lo, hi, (uint32_t)(t0 + j + u));
                     lo = nlo; hi = nhi;
                 }
             }
             for (int j = rows4; j < rows; ++j) {
                 const uint4 nlo = tl[2 * j + 2], nhi = tl[2 * j + 3];
-                row_update<R>(q, k1, k2, lo, hi, (uint32_t)(t0 + j));
+                row_update<R, SECOND>(q, k1, k2, lo, hi, (uint32_t)(t0 + j));
                 lo = nlo; hi = nhi;
             }
             if (tid < nextRows * 2) tile[buf ^ 1][tid] = pre;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void k_hamming_knn2(MatchArgs a)
 // Each wave stages 64 train rows at a time in its own LDS slice (no workgroup barrier in the loop) and reads them back as
 // wave-wide broadcasts like the kernel above.  Output: partial[pair][0][q], i.e. nChunks = 1.
 constexpr int kSmallWaves = 8;
+template <bool SECOND>
 __global__ __launch_bounds__(64 * kSmallWaves) void k_hamming_knn2_small(MatchArgs a)
 {
     __shared__ uint4 rows[kSmallWaves][64 * 2];
@@ -161,9 +163,9 @@ __global__ __launch_bounds__(64 * kSmallWaves) void k_hamming_knn2_small(MatchAr
         __builtin_amdgcn_wave_barrier();
         if (n == 64) {
 #pragma unroll 4
-            for (int j = 0; j < 64; ++j) row_update<1>(q, k1, k2, my[2 * j], my[2 * j + 1], (uint32_t)(t0 + j));
+            for (int j = 0; j < 64; ++j) row_update<1, SECOND>(q, k1, k2, my[2 * j], my[2 * j + 1], (uint32_t)(t0 + j));
         } else {
-            for (int j = 0; j < n; ++j) row_update<1>(q, k1, k2, my[2 * j], my[2 * j + 1], (uint32_t)(t0 + j));
+            for (int j = 0; j < n; ++j) row_update<1, SECOND>(q, k1, k2, my[2 * j], my[2 * j + 1], (uint32_t)(t0 + j));
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -187,9 +189,10 @@ bool knn2_small_applies(int maxQ, int maxT, int npairs)
     return !off && npairs <= 2 && maxQ <= 2048 && maxT <= 4096;
 }
 
-void launch_knn2_small(const MatchArgs& a, int maxQ, int npairs, hipStream_t s)
+void launch_knn2_small(const MatchArgs& a, int maxQ, int npairs, bool needSecond, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_hamming_knn2_small, dim3((maxQ + 63) / 64, npairs), dim3(64 * kSmallWaves), 0, s, a);
+    if (needSecond) hipLaunchKernelGGL(k_hamming_knn2_small<true>, dim3((maxQ + 63) / 64, npairs), dim3(64 * kSmallWaves), 0, s, a);
+    else hipLaunchKernelGGL(k_hamming_knn2_small<false>, dim3((maxQ + 63) / 64, npairs), dim3(64 * kSmallWaves), 0, s, a);
 }
 
 // R = 4 keeps LDS reads at a quarter of the VALU time; small query sets use fewer so that more workgroups exist
@@ -209,13 +212,19 @@ int knn2_query_blocks(int maxQ, int slack)
     return (std::max(maxQ - slack, 1) + 256 * R - 1) / (256 * R);
 }
 
-void launch_knn2(const MatchArgs& a, int maxQ, int qBlocks, int npairs, hipStream_t s)
+void launch_knn2(const MatchArgs& a, int maxQ, int qBlocks, int npairs, bool needSecond, hipStream_t s)
 {
     const int R = knn2_queries_per_lane(maxQ);
     dim3 grid(qBlocks, a.nChunks, npairs);
-    if (R == 4) hipLaunchKernelGGL(k_hamming_knn2<4>, grid, dim3(256), 0, s, a);
-    else if (R == 2) hipLaunchKernelGGL(k_hamming_knn2<2>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_hamming_knn2<1>, grid, dim3(256), 0, s, a);
+    if (needSecond) {
+        if (R == 4) hipLaunchKernelGGL((k_hamming_knn2<4, true>), grid, dim3(256), 0, s, a);
+        else if (R == 2) hipLaunchKernelGGL((k_hamming_knn2<2, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_hamming_knn2<1, true>), grid, dim3(256), 0, s, a);
+    } else {
+        if (R == 4) hipLaunchKernelGGL((k_hamming_knn2<4, false>), grid, dim3(256), 0, s, a);
+        else if (R == 2) hipLaunchKernelGGL((k_hamming_knn2<2, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_hamming_knn2<1, false>), grid, dim3(256), 0, s, a);
+    }
 }
 
 // ---------------------------------------------------------------------------

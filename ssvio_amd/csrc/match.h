@@ -110,9 +110,9 @@ void launch_track(const ssvio_dmatch* last, int nlast, const ssvio_dmatch* cur, 
 
 void launch_pair_summary(const ssvio_dmatch* out, const int* nout, int maxRows, const int* pairs, int npairs, int idMode, int idBase,
                          ssvio_pair_summary* rec, hipStream_t s);
-void launch_knn2(const MatchArgs& a, int maxQ, int qBlocks, int npairs, hipStream_t s);   // qBlocks = knn2_query_blocks(maxQ, slack)
+void launch_knn2(const MatchArgs& a, int maxQ, int qBlocks, int npairs, bool needSecond, hipStream_t s);   // qBlocks = knn2_query_blocks(maxQ, slack)
 bool knn2_small_applies(int maxQ, int maxT, int npairs);                 // small single pairs: chunks = the waves of one workgroup, no merge launch
-void launch_knn2_small(const MatchArgs& a, int maxQ, int npairs, hipStream_t s);   // writes partial[pair][q] (nChunks = 1, pair stride maxRows)
+void launch_knn2_small(const MatchArgs& a, int maxQ, int npairs, bool needSecond, hipStream_t s);   // writes partial[pair][q] (nChunks = 1, pair stride maxRows)
 int  knn2_query_blocks(int maxQ, int slack); // grid.x of k_hamming_knn2 for sets of up to maxQ rows of which the last `slack` are rarely filled
 int  knn2_queries_per_lane(int maxQ);       // R of k_hamming_knn2<R> for this many query rows (tuning knob: SSVIO_MATCH_R)
 void launch_finalize(const FinalizeArgs& a, int npairs, int maxQ, int maxT, hipStream_t s);
