@@ -34,8 +34,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU issue cost of one (query, train) descriptor pair in k_hamming_knn2, from the measured wave64 issue rates in
 # profiles/r1/ubench_valu_rate.txt (tools/ubench/valu_rate.hip on this chip): v_xor_b32 2.46 cycles per wave
 # instruction per SIMD, v_bcnt_u32_b32 / v_lshl_or_b32 / v_med3_u32 / v_min_u32 4.13
-MATCH_CYCLES_PER_PAIR = 8 * 2.46 + 11 * 4.13
+MATCH_CYCLES_PER_PAIR = 8 * 2.46 + 11 * 4.13                        # 8 xor, 8 bcnt, key, median, min: the 2-NN form (ratio test, raw lists)
 VALU_PEAK_PAIRS = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR      # 1024 SIMDs x 2.4 GHz x 64 lanes = 2.42e12 pairs/s
+# MatchByBruteForce and the cross-checks read the nearest neighbour only: the kernel's SECOND = false form drops the median
+MATCH_CYCLES_PER_PAIR_NN = 8 * 2.46 + 10 * 4.13
+VALU_PEAK_PAIRS_NN = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR_NN    # 2.58e12 pairs/s
 # k_hamming_knn2_mfma: 8 x v_mfma_i32_32x32x32_i8 (32 cycles each per SIMD, MI355X_MICROARCH.md matrix table) per 32 x 32 descriptor pairs
 MFMA_PEAK_PAIRS = 256 * 4 * 2.4e9 * 1024 / (8 * 32)                 # 9.83e12 pairs/s at the nominal clock
 
@@ -324,7 +327,7 @@ def batched_matching(rank, world, dev, dist, iters=10):
                 "descriptor_pairs_per_s": float(npairs5) * rows5 * rows5 / dt5, "query_matches_per_s": total5 / dt5, "matches": total5,
                 "sum_dist": int(rec["sum_dist"].sum()),
                 "kernel": "k_hamming_knn2 (VALU xor + popcount, the library's default)",
-                "valu_frac": round(float(npairs5) * rows5 * rows5 / dt5 / (world * VALU_PEAK_PAIRS), 4),
+                "valu_frac": round(float(npairs5) * rows5 * rows5 / dt5 / (world * VALU_PEAK_PAIRS_NN), 4),
                 "mfma_kernel": {"kernel": "k_hamming_knn2_mfma (SSVIO_KERNEL_MFMA), identical records", "ms": round(dt5m * 1e3, 4),
                                 "descriptor_pairs_per_s": float(npairs5) * rows5 * rows5 / dt5m, "speedup": round(dt5 / dt5m, 3),
                                 "roofline": mfma_roofline(float(npairs5) * rows5 * rows5 / dt5m, world),
@@ -867,9 +870,10 @@ def main():
         ms, launches = times["k_hamming_knn2"]
         pairs_eval = sum(nq * nt for nq, nt in pairs_rows)
         rate = pairs_eval / (ms * 1e-3 / launches)
-        valu = {"kernel": "k_hamming_knn2", "descriptor_pairs_per_s": rate, "valu_instructions_per_pair": 19,
-                "issue_cycles_per_pair": round(MATCH_CYCLES_PER_PAIR, 2), "peak_pairs_per_s": VALU_PEAK_PAIRS,
-                "frac": round(rate / VALU_PEAK_PAIRS, 4), "timing": "exclusive pass"}
+        nn = args.match_mode != "ratio"              # the nearest-neighbour form of the kernel (no second key)
+        valu = {"kernel": "k_hamming_knn2", "descriptor_pairs_per_s": rate, "valu_instructions_per_pair": 18 if nn else 19,
+                "issue_cycles_per_pair": round(MATCH_CYCLES_PER_PAIR_NN if nn else MATCH_CYCLES_PER_PAIR, 2), "peak_pairs_per_s": VALU_PEAK_PAIRS_NN if nn else VALU_PEAK_PAIRS,
+                "frac": round(rate / (VALU_PEAK_PAIRS_NN if nn else VALU_PEAK_PAIRS), 4), "timing": "exclusive pass"}
     else:
         valu = None
 
