@@ -937,7 +937,7 @@ __device__ __forceinline__ void sincos_canonical(float xf, float& s, float& c)
 
 // byte masks of the IC patch rows (src/Feature.cpp:84-113 variant of SURVEY App. A4): row v = r - 14 keeps the
 // pixels u in [-d, d) with d = umax[|v|] (row 0: [-15, 16)); byte j of the 32-byte row window is pixel u = j - 16
-constexpr int kDescThreads = 512;             // 8 waves = 16 keypoints per workgroup
+constexpr int kDescThreads = 256;             // 4 waves = 8 keypoints per workgroup (512 / 256 / 128 threads: 303.2 / 307.9 / 305.0 k frames/s sustained: smaller workgroups find room beside k_fast's)
 constexpr int kDescR = 18;                   // |rotated pattern coordinate| <= round(13 * sqrt 2) = 18
 constexpr int kDescRows = 2 * kDescR + 1;     // 37 rows
 constexpr int kDescDw = 10;                   // 37 columns + up to 3 bytes of alignment = 40 bytes per staged row
@@ -1003,8 +1003,13 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
     int incl = (sl & 15) < kl.nlevels ? selCount[frame * kMaxLevels + (sl & 15)] : 0;
     // the 4-KB test pattern goes to LDS once per workgroup; its load travels with the others, its barrier comes after them
     __shared__ float4 spat[256];
-    float4 patv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (threadIdx.x < 256) patv = ((const float4*)c_patf.v)[threadIdx.x];
+    constexpr int kPatPer = (256 + kDescThreads - 1) / kDescThreads;       // records of the pattern per thread
+    float4 patv[kPatPer];
+#pragma unroll
+    for (int i = 0; i < kPatPer; ++i) {
+        patv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (threadIdx.x + i * kDescThreads < 256) patv[i] = ((const float4*)c_patf.v)[threadIdx.x + i * kDescThreads];
+    }
     const int x = in.x & 0xFFFF, y = in.x >> 16, resp = (in.y >> 8) & 0xFF;
     const int pitch = L.pitch;
     const uint8_t* pyrF = pyr + (size_t)frame * pyrFrameBytes;           // wave-uniform bases, 32-bit lane offsets
@@ -1035,7 +1040,8 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
 #pragma unroll
         for (int t = 0; t < 13; ++t) { wb[t] = *(const uint32_t*)(blurF + o); o += step3; }
     }
-    if (threadIdx.x < 256) spat[threadIdx.x] = patv;
+#pragma unroll
+    for (int i = 0; i < kPatPer; ++i) if (threadIdx.x + i * kDescThreads < 256) spat[threadIdx.x + i * kDescThreads] = patv[i];
     __syncthreads();
     // keypoints come out in level-major order (src/Feature.cpp:537-567): this slot's keypoint is number before + idx of the frame
     int total, before;
