@@ -636,9 +636,9 @@ def main():
     ap.add_argument("--no-batched-matching", action="store_true", help="skip the configs[3]/[4] matching section")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip configs[0], configs[1] streamed, configs[2] and the sustained run (N = 1 only anyway)")
     ap.add_argument("--sync-steps", action="store_true", help="host waits for every step (latency mode)")
-    ap.add_argument("--streams", type=int, default=6, help="steps in flight: step i runs on handle pair i %% streams, each pair on its own HIP stream "
-                    "(round 3, 4 / 5 / 6 / 7 in flight: 293.5 / 289.9 / 296-299 / 292.8 k frames/s over the 20 default steps, 325 / 328 / 333 / 328 k with the "
-                    "matrix-core matcher, tools/probe/streams_sweep.sh; round 2, 2 / 3 / 4 / 6: 260 / 254 / 262 / 263 k sustained)")
+    ap.add_argument("--streams", type=int, default=4, help="steps in flight: step i runs on handle pair i %% streams, each pair on its own HIP stream "
+                    "(round 3, final tree, 4 / 6 / 8 in flight: 301-303 / 298-301 / 298 k frames/s over 20 steps, 310 / 308 / 307 k sustained; with the matrix-core matcher "
+                    "335 / 340 / 336 k sustained, tools/probe/streams_sweep.sh; before k_describe's workgroups shrank to 256 threads six in flight was ahead, 296-299 against 293.5 k)")
     ap.add_argument("--no-kernel-events", action="store_true", help="no hipEvent pairs inside the timed region (the roofline entry then uses "
                     "the exclusive pass); lets the library replay its captured hipGraph, which it does not do while kernels are bracketed")
     ap.add_argument("--all-kernel-events", action="store_true", help="hipEvent pairs around every kernel in the timed region (slower)")

@@ -1,7 +1,7 @@
-# GPU-box probe: steps in flight on the default bench line (20 timed steps as the default run, then the sustained figure)
+# GPU-box probe: steps in flight on the default bench line (20 timed steps as the driver runs it, then the sustained figure)
 for rep in 1 2; do
-for n in 4 5 6 7; do
-  timeout -k 10 200 python bench.py --streams $n --no-cpu-baseline --no-batched-matching --no-next-rows > gpurun_out/tmp_b.json 2>/dev/null || exit 1
+for n in 4 6 8; do
+  timeout -k 10 200 python bench.py --streams $n --steps 20 --no-cpu-baseline --no-batched-matching --no-next-rows > gpurun_out/tmp_b.json 2>/dev/null || exit 1
   python3 - $n <<'PY'
 import json,sys
 d=json.loads(open('gpurun_out/tmp_b.json').read().strip().splitlines()[-1])
