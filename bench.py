@@ -43,6 +43,7 @@ VALU_PEAK_PAIRS_NN = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR_NN    # 2.58e1
 MFMA_PEAK_PAIRS = 256 * 4 * 2.4e9 * 1024 / (8 * 32)                 # 9.83e12 pairs/s at the nominal clock
 
 
+DEFAULT_BATCH = 768            # frames per step of the default line
 PROFILE_DIR = os.path.join(ROOT, "profiles", "r3")
 PMC_FILE = os.path.join(PROFILE_DIR, "r3_final_pmc_hbm.json")
 
@@ -623,8 +624,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step (96 / 128 / 160 / 192 / 256 with four steps in flight: 247 / 251 / 257 / 261 / 264 k frames/s "
-                    "over a 20-step region, tools/probe/k20_grid.sh: the region's fill and drain weigh less the longer it is)")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="frames per step (round 3, 256 / 384 / 512 / 768 / 1024 with four steps in flight: 299 / 302 / 298 / 306-314 / 309 k frames/s "
+                    "over a 20-step region, 308 / 304 / 300 / 311 / 311 k sustained, tools/probe/k20_grid.sh: the region's fill and drain weigh less the longer a step is, and so do "
+                    "the ramps and tails of every launch; round 2, 96 / 128 / 160 / 192 / 256: 247 / 251 / 257 / 261 / 264 k)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--features", type=int, default=1000)
@@ -839,7 +841,7 @@ def main():
                       "alg_bytes_per_launch": int(ab), "GBps": round(ab / (avg_us * 1e-6) / 1e9, 1) if avg_us > 0 else None}
     if dom_launches == 0:                      # --no-kernel-events: the exclusive pass is the only measurement
         dom_ms, dom_launches = times[dom]
-    prof_ok = profiles_current() and (B, W, H, args.features) == (256, 640, 480, 1000)
+    prof_ok = profiles_current() and (B, W, H, args.features) == (DEFAULT_BATCH, 640, 480, 1000)     # the committed PMC figures are per launch of the default command
     dom_avg_s = dom_ms * 1e-3 / dom_launches
     dom_bytes = algorithmic_bytes(dom, B, px, int(counts.sum()), pairs_rows)
     excl_s = times[dom][0] * 1e-3 / times[dom][1]

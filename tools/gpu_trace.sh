@@ -11,3 +11,7 @@ echo "== 256-frame launches, one step in flight, k_blur after k_fast"
 SSVIO_BLUR_AFTER_FAST=1 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_256 -- python3 $R/tools/timing_probe.py 256 > $R/gpurun_out/${tag}_256.log 2>&1
 grep batch $R/gpurun_out/${tag}_256.log
 python3 $R/tools/trace_summary.py $R/gpurun_out/${tag}_256
+echo "== 768-frame launches (the bench line's default step), one step in flight, k_blur after k_fast"
+SSVIO_BLUR_AFTER_FAST=1 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_768 -- python3 $R/tools/timing_probe.py 768 > $R/gpurun_out/${tag}_768.log 2>&1
+grep batch $R/gpurun_out/${tag}_768.log
+python3 $R/tools/trace_summary.py $R/gpurun_out/${tag}_768

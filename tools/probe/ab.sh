@@ -3,7 +3,7 @@ cp ssvio_amd/libssvio_gpu.so /tmp/lib_new.so
 for i in 1 2 3; do
   for v in new old; do
     if [ $v = new ]; then cp /tmp/lib_new.so ssvio_amd/libssvio_gpu.so; else cp tools/probe/lib_old.bin ssvio_amd/libssvio_gpu.so; fi
-    timeout -k 10 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-batched-matching --no-next-rows > gpurun_out/tmp_b.json 2>/dev/null || exit 1
+    timeout -k 10 200 python bench.py --batch 256 --steps 40 --warmup 5 --no-cpu-baseline --no-batched-matching --no-next-rows > gpurun_out/tmp_b.json 2>/dev/null || exit 1
     python3 - $v <<'PY'
 import json,sys
 d=json.loads(open('gpurun_out/tmp_b.json').read().strip().splitlines()[-1])

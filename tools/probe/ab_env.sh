@@ -4,7 +4,7 @@ kv=$1; shift
 for i in 1 2 3; do
   for v in off on; do
     if [ $v = on ]; then export "$kv"; else unset "${kv%%=*}"; fi
-    timeout -k 10 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-batched-matching --no-next-rows "$@" > gpurun_out/tmp_b.json 2>/dev/null || exit 1
+    timeout -k 10 200 python bench.py --batch 256 --steps 40 --warmup 5 --no-cpu-baseline --no-batched-matching --no-next-rows "$@" > gpurun_out/tmp_b.json 2>/dev/null || exit 1
     python3 - $v "$kv" <<'PY'
 import json,sys
 d=json.loads(open('gpurun_out/tmp_b.json').read().strip().splitlines()[-1])
