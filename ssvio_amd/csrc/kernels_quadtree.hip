@@ -21,7 +21,10 @@
 namespace ssvio {
 
 constexpr int kQtThreads = 1024;
-constexpr int kQtRegKeys = 8;            // keys per thread kept in registers (8192 per level); the rest stay in HBM scratch
+// keys per thread kept in registers (and, in the 256-node short form, in LDS); the rest stay in HBM scratch.  8 / 4 / 3 / 2: the short form's
+// workgroup takes 36.6 / 28.4 / 26.4 / 24.3 KB of LDS and 118 / 90 / .. VGPRs, i.e. 4 / 5 / 6 / 6+ fit a CU beside the other steps' kernels:
+// 311 / 318 / 319 / 317 k frames/s sustained on the bench line (768-frame steps), although the kernel alone is fastest at 2 (280 us against 475)
+constexpr int kQtRegKeys = 4;
 
 struct QtShared {
     int wsum[16];
@@ -757,8 +760,8 @@ void quadtree_prepare()
 int launch_quadtree(const QtArgs& a, int maxAlive, int nlevels, int batch, hipStream_t s)
 {
     quadtree_prepare();
-    // the smallest node capacity that holds quota + 3: 19 KB of LDS at 256 nodes (73 KB at 1024), so that the workgroups of
-    // other kernels (k_fast, k_describe of the step in flight beside this one) still fit on the CU
+    // the smallest node capacity that holds quota + 3: 28 KB of LDS at 256 nodes with the level's first 1024 keys (79 KB at 1024 nodes), so that the
+    // workgroups of other kernels (k_fast, k_describe of the steps in flight beside this one) still fit on the CU
     static const bool longForm = getenv("SSVIO_QUADTREE_LONG") != nullptr;      // measuring knob: the round structure with ~15 barriers
     unsigned maxRawCap = 0;
     for (int l = 0; l < nlevels; ++l) maxRawCap = std::max(maxRawCap, a.kl.lv[l].rawCap);
