@@ -35,7 +35,7 @@ static void pick_chunks(int maxQ, int maxT, int npairs, bool mfma, int slack, in
         return;
     }
     static const int forcedRows = [] { const char* e = getenv("SSVIO_MATCH_CHUNKROWS"); return e ? atoi(e) : 0; }();   // tuning knob
-    static const int target = [] { const char* e = getenv("SSVIO_MATCH_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+    static const int target = [] { const char* e = getenv("SSVIO_MATCH_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();    // workgroups per launch the chunking aims at (2048 until round 3: 2-5 % slower on every shape of match_r_sweep.py)
     qBlocksOut = knn2_query_blocks(maxQ, slack);
     const long qBlocks = (long)qBlocksOut * npairs;
     long want = (target + qBlocks / 2) / qBlocks;

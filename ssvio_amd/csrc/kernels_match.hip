@@ -200,7 +200,11 @@ int knn2_queries_per_lane(int maxQ)
 {
     static const int forced = [] { const char* e = getenv("SSVIO_MATCH_R"); return e ? atoi(e) : 0; }();
     if (forced == 1 || forced == 2 || forced == 4) return forced;
-    return maxQ > 2048 ? 4 : maxQ > 512 ? 2 : 1;
+    // one query per lane everywhere since the nearest-neighbour form of the kernel (round 3): with fewer registers per lane the extra
+    // waves hide the LDS broadcasts better than R = 2 or 4 save them (tools/probe/match_r_sweep.py: 1006 / 2000 / 4000 / 8000-row sets,
+    // R = 1 against the old choice: +3 %, +2 %, +1 %, +3 %; +7 % on the bench step's matcher with the other steps' kernels beside it)
+    (void)maxQ;
+    return 1;
 }
 
 // query blocks of a launch: those the sets are expected to fill.  A set handed over by the extractor can hold 32 rows more than it
