@@ -551,9 +551,10 @@ def extra_configs(dev, frames_vga, with_cpu=True):
         dt = time.perf_counter() - t0
         p.close()
         return round(n * Bx / dt, 1)
-    dv = torch.from_numpy(synth.frame_stream(1000, 128, H, W)).to(dev)
-    out.append({"config": "ORB extraction alone, device-resident: 640x480 / 1000 features in 128-frame steps, 1920x1080 / 4000 features in %d-frame steps, 4 in flight" % B3,
-                "value": extract_only(dv, 128, W, H, 1000, 4, 120), "unit": "frames/s", "value_1080p": extract_only(d3, B3, W3, H3, 4000, 4, 60)})
+    Bv = int(os.environ.get("SSVIO_BENCH_EXTRACT_BATCH", str(min(len(frames_vga), DEFAULT_BATCH))))
+    dv = torch.from_numpy(np.ascontiguousarray(frames_vga[:Bv])).to(dev) if Bv <= len(frames_vga) else torch.from_numpy(synth.frame_stream(1000, Bv, H, W)).to(dev)
+    out.append({"config": "ORB extraction alone, device-resident: 640x480 / 1000 features in %d-frame steps, 1920x1080 / 4000 features in %d-frame steps, 4 in flight" % (Bv, B3),
+                "value": extract_only(dv, Bv, W, H, 1000, 4, max(20, 15360 // Bv)), "unit": "frames/s", "value_1080p": extract_only(d3, B3, W3, H3, 4000, 4, 60)})
     return out
 
 
