@@ -204,26 +204,36 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
 constexpr int kResizeSrcRows = 12;
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 
+// NF = 2 or 4: the wave's halves (quarters) take the same 32 (16) quads of the same strip in consecutive frames -- control flow and
+// tables are the strip's, so nothing diverges; only the lane offsets differ by a frame.  Rows are then dealt in chunks of 32 (16) quads
+// instead of 64, which is what the upper pyramid levels need: a 257-px row is 67 quads - 2 x 64 lanes at 52 %, 5 x 16 at 84 %.
+template <int NF>
 __global__ __launch_bounds__(256) void k_resize_quad(uint8_t* __restrict__ pyr, size_t pyrFrameBytes,
                                                      unsigned long long srcOff, int srcPitch,
                                                      unsigned long long dstOff, int dstPitch, int nq, int dh, int rows,
                                                      const ResizeQuad* __restrict__ qtab, const short4* __restrict__ ytab,
                                                      int gx, int blocksPerFrame, int batch)
 {
-    int frame, blk;
-    xcd_frame_block(blockIdx.x, blocksPerFrame, batch, frame, blk);
+    constexpr int CH = 64 / NF;                       // quads per frame in a wave
+    int frame, blk;                                   // NF > 1: `frame` is the first frame of the wave's group, `batch` the number of frames
+    xcd_frame_block(blockIdx.x, blocksPerFrame, (batch + NF - 1) / NF, frame, blk);
+    frame *= NF;
     const int by = blk / gx, bx = blk - by * gx;
-    const int qi = bx * 64 + (threadIdx.x & 63);
+    const int sub = (threadIdx.x & 63) / CH;          // which frame of the group
+    const int qi = bx * CH + (threadIdx.x & (CH - 1));
     const int strip = __builtin_amdgcn_readfirstlane(by * 4 + (threadIdx.x >> 6));
     const int yBeg = strip * rows;
     if (yBeg >= dh) return;
     const int yEnd = min(yBeg + rows, dh);
-    const bool live = qi < nq;
-    const ResizeQuad e = qtab[live ? qi : 0];
-    const uint32_t b = e.bOff & 0xFFFFFF, off = e.bOff >> 24;
+    const bool frameOk = frame + sub < batch;                                  // the last group of a batch may be short
+    const bool live = qi < nq && frameOk;
+    const ResizeQuad e = qtab[qi < nq ? qi : 0];
+    const uint32_t off = e.bOff >> 24;
+    const uint32_t fo = frameOk ? (uint32_t)sub * (uint32_t)pyrFrameBytes : 0u;           // lane offset of the group's frame (host: NF frames < 2 GB)
+    const uint32_t b = (e.bOff & 0xFFFFFF) + (fo >> 2);                      // in dwords, as the table's
     const uint8_t* S = pyr + (size_t)frame * pyrFrameBytes + srcOff;
     uint8_t* D = pyr + (size_t)frame * pyrFrameBytes + dstOff;               // wave-uniform; the lane's quad starts 4 qi - kPadX into a row
-    const uint32_t dq = 4u * (uint32_t)qi;                                   // ... taken from D - kPadX, so that the offsets stay unsigned
+    const uint32_t dq = 4u * (uint32_t)qi + fo;                              // ... taken from D - kPadX, so that the offsets stay unsigned
     // wave-uniform, and told so: 16-bit loads come back in VGPRs, and with them the row addresses below would be 64-bit VALU arithmetic
     const int sBeg = __builtin_amdgcn_readfirstlane(ytab[yBeg].x), sEnd = __builtin_amdgcn_readfirstlane(ytab[yEnd - 1].y);
     // per pixel of the quad: the selector that lays its taps out as (tap0, 0, tap1, 0) and its coefficients (0 .. 2048) as a u16 pair
@@ -383,8 +393,27 @@ void launch_resize(uint8_t* pyr, size_t pyrFrameBytes, const KLevels& kl, int le
     const int dw = kl.lv[level].w, dh = kl.lv[level].h;
     if (mode == 1) {
         const int nq = (dw + 2 * kPadX + 3) / 4;
+        // two or four frames per wave where chunks of 32 / 16 quads waste fewer lanes than chunks of 64 (and the group stays inside 32-bit offsets)
+        static const bool noGroup = getenv("SSVIO_RESIZE_NO_PAIR") != nullptr;
+        auto lanes = [nq](int ch) { return (nq + ch - 1) / ch * ch; };
+        const bool fits = !noGroup && pyrFrameBytes % 4 == 0 && 4 * pyrFrameBytes < (1ull << 31);
+        // (four frames per wave, chunks of 16 quads, was measured too: fewer idle lanes still, but 64-byte row segments per frame --
+        // the seven launches went from 66.0 back to 68.2 us on average per 768 frames; SSVIO_RESIZE_QUARTERS=1 selects it)
+        static const bool quarters = getenv("SSVIO_RESIZE_QUARTERS") != nullptr;
+        const int nf = (quarters && fits && batch >= 4 && lanes(16) < lanes(32)) ? 4 : (fits && batch >= 2 && lanes(32) < lanes(64)) ? 2 : 1;
+        if (nf > 1) {
+            const int ch = 64 / nf, gx = (nq + ch - 1) / ch, bpf = gx * ((dh + 4 * rows - 1) / (4 * rows));
+            const dim3 grid(bpf * ((batch + nf - 1) / nf));
+            if (nf == 4) hipLaunchKernelGGL(k_resize_quad<4>, grid, dim3(256), 0, s, pyr, pyrFrameBytes,
+                               kl.lv[level - 1].offset, kl.lv[level - 1].pitch, kl.lv[level].offset, kl.lv[level].pitch, nq, dh, rows,
+                               (const ResizeQuad*)(tabs + quadTabOff), (const short4*)(tabs + yTabOff), gx, bpf, batch);
+            else hipLaunchKernelGGL(k_resize_quad<2>, grid, dim3(256), 0, s, pyr, pyrFrameBytes,
+                               kl.lv[level - 1].offset, kl.lv[level - 1].pitch, kl.lv[level].offset, kl.lv[level].pitch, nq, dh, rows,
+                               (const ResizeQuad*)(tabs + quadTabOff), (const short4*)(tabs + yTabOff), gx, bpf, batch);
+            return;
+        }
         const int gx = (nq + 63) / 64, bpf = gx * ((dh + 4 * rows - 1) / (4 * rows));
-        hipLaunchKernelGGL(k_resize_quad, dim3(bpf * batch), dim3(256), 0, s, pyr, pyrFrameBytes,
+        hipLaunchKernelGGL(k_resize_quad<1>, dim3(bpf * batch), dim3(256), 0, s, pyr, pyrFrameBytes,
                            kl.lv[level - 1].offset, kl.lv[level - 1].pitch, kl.lv[level].offset, kl.lv[level].pitch, nq, dh, rows,
                            (const ResizeQuad*)(tabs + quadTabOff), (const short4*)(tabs + yTabOff), gx, bpf, batch);
         return;
