@@ -223,7 +223,7 @@ static void fill_klevels(const PyramidGeom& g, KLevels& k)
         K.w = L.w; K.h = L.h; K.pitch = L.pitch; K.offset = L.offset;
         K.nCols = L.nCols; K.nRows = L.nRows; K.wCell = L.wCell; K.hCell = L.hCell; K.cellBase = L.cellBase;
         K.fastTileBase = L.fastTileBase; K.fastTilesX = L.fastTilesX; K.fastTileBaseT = L.fastTileBaseT; K.fastTileH = L.fastTileH; K.fastTileHT = L.fastTileHT;
-        K.blurStripBase = L.blurStripBase; K.blurStripsX = L.blurStripsX; K.blurIters = L.blurIters;
+        K.blurStripBase = L.blurStripBase; K.blurStripsX = L.blurStripsX; K.blurIters = L.blurIters; K.blurPanelStride = L.blurPanelStride;
         K.quota = L.quota; K.kpSize = L.kpSize; K.scale = L.scale;
         K.rawBase = (unsigned)L.slotBase; K.rawCap = (unsigned)L.slotCap * L.nCols * L.nRows;
         K.selBase = L.selBase; K.nIni = L.nIni; K.hX = L.hX;
@@ -841,7 +841,16 @@ int ssvio_orb_debug_level_image(ssvio_orb* h, int frame, int level, int blurred,
     const LevelGeom& L = h->geom.lv[level];
     if (dst_stride < L.w) { set_error("dst_stride too small"); return SSVIO_ERR_INVALID; }
     SSVIO_HIP(hipSetDevice(h->device));
-    const uint8_t* src = (blurred ? h->d_blur : h->d_pyr) + (size_t)frame * h->geom.frameBytes + L.offset;
+    if (blurred) {      // stored as 32-px-wide column panels (geometry.cpp): fetched whole, put back into rows here
+        const int np = (L.w + 31) / 32;
+        std::vector<uint8_t> tmp((size_t)np * L.blurPanelStride);
+        SSVIO_HIP(hipMemcpyAsync(tmp.data(), h->d_blur + (size_t)frame * h->geom.frameBytes + (L.offset - 64), tmp.size(), hipMemcpyDeviceToHost, h->stream));
+        SSVIO_HIP(hipStreamSynchronize(h->stream));
+        for (int y = 0; y < L.h; ++y)
+            for (int x = 0; x < L.w; ++x) dst[(size_t)y * dst_stride + x] = tmp[(size_t)(x >> 5) * L.blurPanelStride + 32 * y + (x & 31)];
+        return SSVIO_OK;
+    }
+    const uint8_t* src = h->d_pyr + (size_t)frame * h->geom.frameBytes + L.offset;
     SSVIO_HIP(hipMemcpy2DAsync(dst, dst_stride, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, h->stream));
     SSVIO_HIP(hipStreamSynchronize(h->stream));
     return SSVIO_OK;

@@ -50,6 +50,7 @@ struct LevelGeom {
     int fastTileBase, fastTilesX, fastTilesY, fastTileH;   // k_fast tiles over the tested region: 64 px wide, fastTileH <= 32 rows
     int fastTileBaseT, fastTilesYT, fastTileHT;            // ... and the tall form (<= 64 rows) used for large batches
     int blurStripBase, blurStripsX, blurStripsY, blurIters;   // k_blur strips: 120 px wide, 7*blurIters-6 rows tall
+    int blurPanelStride;      // the blurred level is stored as 32-px-wide column panels of this many bytes (its own layout: only k_blur and k_describe see it)
     size_t tabOffset;         // offset (in shorts) of this level's resize tables
 };
 
@@ -73,6 +74,7 @@ struct KLevel {
     int cellBase;
     int fastTileBase, fastTilesX, fastTileBaseT, fastTileH, fastTileHT;
     int blurStripBase, blurStripsX, blurIters;
+    int blurPanelStride;              // blurred pixel (x, y) of the level: panel base (offset - 64) + (x >> 5) * blurPanelStride + 32 * y + (x & 31)
     int quota, kpSize;
     float scale;
     unsigned long long offset;        // byte offset of pixel (0,0) inside a frame's pyramid

@@ -101,6 +101,13 @@ int build_geometry(const ExtractorTables& t, int width, int height, PyramidGeom&
             L.blurStripsY = (L.h + (7 * L.blurIters - 6) - 1) / (7 * L.blurIters - 6);
         }
         L.blurStripBase = tiles; tiles += L.blurStripsX * L.blurStripsY;
+        // the blurred level in 32-px-wide column panels (a 128-byte line = 4 rows of a panel): the 37 x 37 window k_describe samples touches
+        // ~23 lines instead of ~48 in row-major order.  Columns up to w + 2 and rows up to h are addressed (alignment, three-row passes).
+        L.blurPanelStride = ((L.h + 2) * 32 + 127) & ~127;
+        if ((size_t)((L.w + 3 + 31) / 32) * (size_t)L.blurPanelStride > (size_t)L.pitch * (L.h + 1)) {
+            set_error("level %d is %dx%d: the blurred level's panel layout does not fit its slot", l, L.w, L.h);
+            return SSVIO_ERR_GEOMETRY;
+        }
         // k_fast tiles cover the tested region only: columns from kFastX0 = 16 (aligned) to w - 20, rows 19 .. h - 20 split evenly
         {
             const int cols = L.w - kEdge - kFastX0, rows = L.h - 2 * kEdge;          // both >= 24: a level holds at least one 30-px cell

@@ -804,7 +804,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     const int y0 = sy * rows;
     const bool writer = lane >= 1 && lane <= 30 && x < w;
     const uint32_t lbase = (uint32_t)L.offset + (uint32_t)min(x, (w + 3) & ~3);     // offset of this lane's dword in row 0 (x >= -4, offset >= 64)
-    uint32_t sOff = (uint32_t)L.offset + (uint32_t)x + (uint32_t)(y0 - 6) * (uint32_t)pitch;   // store offset of step 0's output row (used from step 6 on)
+    // the blurred level is written as 32-px-wide column panels (geometry.cpp): the lane's four pixels sit in one panel, a row further is 32 bytes on.
+    // Store offset of step 0's output row (used from step 6 on; lanes that never store may compute anything)
+    uint32_t sOff = (uint32_t)(L.offset - 64) + ((uint32_t)x >> 5) * (uint32_t)L.blurPanelStride + ((uint32_t)x & 31u) + (uint32_t)(y0 - 6) * 32u;
     uint32_t r0[4], r1[4], r2[4], r3[4], r4[4], r5[4], r6[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) r0[i] = r1[i] = r2[i] = r3[i] = r4[i] = r5[i] = r6[i] = 0;
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
         const int yout = y0 + s0 + (S) - 6;                                                          \
         if (s0 + (S) >= 6 && writer && yout < h)                                                     \
             *(uint32_t*)(fdst + sOff) = blur_col4(A, B, C, D, E, F, G);                              \
-        sOff += (uint32_t)pitch;                                                                     \
+        sOff += 32u;                                                                                 \
     }
     uint32_t cur[7], nxt[7];
 #pragma unroll
@@ -1052,8 +1054,9 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
     // level offsets and pitches are multiples of 64 and the buffers are 256-byte aligned: alignment shifts come from x alone
     uint32_t ip = centerOff - 14 * pitch - 16;                              // intensity window: rows -14..14, pixels u = -16..
     const unsigned sh = ip & 3u; ip -= sh;
-    uint32_t bp = centerOff - kDescR * pitch - kDescR;                      // blurred window: rows/cols -18..18
-    const unsigned shb = bp & 3u; bp -= shb;
+    // blurred window: rows / columns -18 .. 18, out of the panel layout k_blur writes (32-px-wide column panels, a 128-byte line = 4 rows of a
+    // panel: the window touches ~23 lines instead of ~48).  A lane's dword never straddles two panels.
+    const unsigned shb = (unsigned)(x - kDescR) & 3u;
     // three rows per pass: lane -> (row ri of the pass, dword ii) once, then one add per pass (27 lanes of the half busy on the 9-dword
     // intensity rows, 30 on the 10-dword blurred rows; the last pass reads one or two rows below the window - inside the level's
     // buffer, the keypoint being kEdge = 19 rows from the bottom and the buffer one row taller than the level - and drops them)
@@ -1065,9 +1068,10 @@ __global__ __launch_bounds__(kDescThreads) void k_describe(const uint8_t* __rest
         uint32_t o = ip + __umul24(ri, (unsigned)pitch) + 4 * ii;
 #pragma unroll
         for (int t = 0; t < 10; ++t) { wi[t] = *(const uint32_t*)(pyrF + o); o += step3; }
-        o = bp + __umul24(rb, (unsigned)pitch) + 4 * ib;
+        const unsigned xa = ((unsigned)(x - kDescR) & ~3u) + 4 * ib;
+        o = (uint32_t)(L.offset - 64) + (xa >> 5) * (unsigned)L.blurPanelStride + (xa & 31u) + 32u * (unsigned)(y - kDescR + (int)rb);
 #pragma unroll
-        for (int t = 0; t < 13; ++t) { wb[t] = *(const uint32_t*)(blurF + o); o += step3; }
+        for (int t = 0; t < 13; ++t) { wb[t] = *(const uint32_t*)(blurF + o); o += 96u; }
     }
 #pragma unroll
     for (int i = 0; i < kPatPer; ++i) if (threadIdx.x + i * kDescThreads < 256) spat[threadIdx.x + i * kDescThreads] = patv[i];
