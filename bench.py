@@ -31,14 +31,15 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# VALU issue cost of one (query, train) descriptor pair in k_hamming_knn2, from the measured wave64 issue rates in
-# profiles/r1/ubench_valu_rate.txt (tools/ubench/valu_rate.hip on this chip): v_xor_b32 2.46 cycles per wave
-# instruction per SIMD, v_bcnt_u32_b32 / v_lshl_or_b32 / v_med3_u32 / v_min_u32 4.13
-MATCH_CYCLES_PER_PAIR = 8 * 2.46 + 11 * 4.13                        # 8 xor, 8 bcnt, key, median, min: the 2-NN form (ratio test, raw lists)
-VALU_PEAK_PAIRS = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR      # 1024 SIMDs x 2.4 GHz x 64 lanes = 2.42e12 pairs/s
+# VALU issue cost of one (query, train) descriptor pair in k_hamming_knn2 at the two issue rates of the chip: 2 cycles per wave
+# instruction per SIMD for v_xor_b32, 4 for v_bcnt_u32_b32 / v_lshl_or_b32 / v_med3_u32 / v_min_u32.  (The dependent-chain
+# micro-benchmarks of profiles/r1/ubench_valu_rate.txt read 2.46 and 4.13; rounds 1-3 priced the roof with those, until the kernel's
+# nearest-neighbour form ran the full configs[4] walk at 2.66e12 pairs/s, 3 % above that price: the nominal rates are the roof.)
+MATCH_CYCLES_PER_PAIR = 8 * 2.0 + 11 * 4.0                          # 8 xor, 8 bcnt, key, median, min: the 2-NN form (ratio test, raw lists)
+VALU_PEAK_PAIRS = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR      # 1024 SIMDs x 2.4 GHz x 64 lanes = 2.62e12 pairs/s
 # MatchByBruteForce and the cross-checks read the nearest neighbour only: the kernel's SECOND = false form drops the median
-MATCH_CYCLES_PER_PAIR_NN = 8 * 2.46 + 10 * 4.13
-VALU_PEAK_PAIRS_NN = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR_NN    # 2.58e12 pairs/s
+MATCH_CYCLES_PER_PAIR_NN = 8 * 2.0 + 10 * 4.0
+VALU_PEAK_PAIRS_NN = 256 * 4 * 2.4e9 * 64 / MATCH_CYCLES_PER_PAIR_NN    # 2.81e12 pairs/s
 # k_hamming_knn2_mfma: 8 x v_mfma_i32_32x32x32_i8 (32 cycles each per SIMD, MI355X_MICROARCH.md matrix table) per 32 x 32 descriptor pairs
 MFMA_PEAK_PAIRS = 256 * 4 * 2.4e9 * 1024 / (8 * 32)                 # 9.83e12 pairs/s at the nominal clock
 
