@@ -425,6 +425,8 @@ def extra_configs(dev, frames_vga, with_cpu=True):
     frames = synth.frame_stream(2000, nfr, H, W)
     pinned = torch.from_numpy(frames).pin_memory()
     p = Pipeline(dev, 1000, S, torch_streams=True)
+    if os.environ.get("SSVIO_BENCH_STREAMED_GRAPH", "0") == "1":
+        for e in p.exs: e.set_graph(True)       # one submission per step beside the copies: no gain (162 k against 163-164 k frames/s over 0.5-s regions; 0.1-s regions scatter by +-10 %)
     ncopy = int(os.environ.get("SSVIO_BENCH_COPY_STREAMS", "1"))      # a batch goes up in ncopy slices, one copy stream each (measured: 1 -> 122 k, 2 -> 82 k, 4 -> 65 k frames/s: more streams crowd the 4 hardware queues)
     copy_sts = [torch.cuda.Stream(device=dev) for _ in range(ncopy)]
     nbuf = S + int(os.environ.get("SSVIO_BENCH_STREAMED_SPARE_BUFFERS", "3"))
@@ -452,7 +454,7 @@ def extra_configs(dev, frames_vga, with_cpu=True):
     for _ in range(8):
         sstep()
     p.sync(); torch.cuda.synchronize()
-    ns = 60 if B >= 256 else 120
+    ns = 300 if B >= 256 else 600          # ~0.5 s: shorter regions scatter by +-10 % from run to run
     t0 = time.perf_counter()
     for _ in range(ns):
         sstep()

@@ -134,6 +134,13 @@ int  ssvio_orb_pyramid_level(ssvio_orb* h, int frame, int level, uint8_t* dst, i
 int  ssvio_orb_set_export_pyramid(ssvio_orb* h, int enable);
 int  ssvio_orb_exported_pyramid_level(ssvio_orb* h, int level, const uint8_t** base, int* stride, int* lw, int* lh);
 
+/* Replay the extractor's launch sequence (pyramid, FAST, blur beside the quadtree, describe: ~12 launches, one fork / join) as a hipGraph,
+ * captured once per (batch size, buffer generation) -- what SSVIO_GRAPH=1 does for every handle of a process, here per handle.  Same
+ * results.  No counterpart in the reference (src/Feature.cpp:503-568 is one synchronous call); for callers that want one submission per
+ * call.  Off by default: on this stack the plain launches are 2-3 % ahead with device-resident frames and level with the replay when the
+ * same host thread streams the frames up from pinned memory (163-164 k against 162 k frames/s, DESIGN.md sections 4 and 6). */
+int  ssvio_orb_set_graph(ssvio_orb* h, int enable);
+
 /* stage-level taps for parity tests (last call, frame `frame`) */
 int  ssvio_orb_debug_level_image(ssvio_orb* h, int frame, int level, int blurred, uint8_t* dst, int dst_stride);
 /* candidates before the quadtree: x,y relative to (minBorderX,minBorderY), response; returns count via *n */

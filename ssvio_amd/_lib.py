@@ -67,6 +67,7 @@ SYMBOLS = {
     "ssvio_orb_last_counts": (_i, [_vp, _i, _vp]),
     "ssvio_orb_pyramid_level": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     "ssvio_orb_set_export_pyramid": (_i, [_vp, _i]),
+    "ssvio_orb_set_graph": (_i, [_vp, _i]),
     "ssvio_orb_exported_pyramid_level": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "ssvio_orb_debug_level_image": (_i, [_vp, _i, _i, _i, _vp, _i]),
     "ssvio_orb_debug_candidates": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp]),

@@ -201,6 +201,7 @@ struct ssvio_orb {
     bool haveResults = false;
     // the launch sequence behind k_level0 as a hipGraph (one per batch size and buffer generation), replayed by later calls
     hipGraphExec_t gexec = nullptr; int gBatch = 0; unsigned gGen = 0, allocGen = 1; bool graphFailed = false;
+    bool useGraph = false;         // ssvio_orb_set_graph: this handle replays its launch sequence whatever SSVIO_GRAPH says
 };
 
 static void orb_free_buffers(ssvio_orb* h)
@@ -512,7 +513,7 @@ static int orb_run(ssvio_orb* h, int batch, bool wait = true)
     hipStream_t s = h->stream;
     h->hostRawValid = false;
     bool launched = false;
-    if (graphs_enabled() && !h->hostQuadtree && !h->prof.enabled && !h->graphFailed && !h->hostKp && !h->exportNow) {
+    if ((graphs_enabled() || h->useGraph) && !h->hostQuadtree && !h->prof.enabled && !h->graphFailed && !h->hostKp && !h->exportNow) {
         if (!h->gexec || h->gBatch != batch || h->gGen != h->allocGen) {
             if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
             quadtree_prepare();                                   // function attributes are set outside the capture
@@ -877,6 +878,13 @@ int ssvio_orb_pyramid_level(ssvio_orb* h, int frame, int level, uint8_t* dst, in
         memcpy(dst + (size_t)(kEdge - i) * dst_stride, dst + (size_t)(kEdge + refl101_host(-i, L.h)) * dst_stride, (size_t)L.w + 2 * kEdge);
         memcpy(dst + (size_t)(kEdge + L.h - 1 + i) * dst_stride, dst + (size_t)(kEdge + refl101_host(L.h - 1 + i, L.h)) * dst_stride, (size_t)L.w + 2 * kEdge);
     }
+    return SSVIO_OK;
+}
+
+int ssvio_orb_set_graph(ssvio_orb* h, int enable)
+{
+    if (orb_check(h)) return SSVIO_ERR_INVALID;
+    h->useGraph = enable != 0;
     return SSVIO_OK;
 }
 

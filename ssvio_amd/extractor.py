@@ -126,6 +126,10 @@ class ORBextractor:
         return out
 
     # ---- stage taps (tests)
+    def set_graph(self, on):
+        """replay this handle's launch sequence as a hipGraph (ssvio_orb_set_graph); same results"""
+        L.check(L.lib().ssvio_orb_set_graph(self._h, int(on)))
+
     def set_export_pyramid(self, on):
         """every single-frame Extract / ExtractRGB also stores the rimmed pyramid into pinned host memory (mvImagePyramid, include/Feature.h:45)"""
         L.check(L.lib().ssvio_orb_set_export_pyramid(self._h, int(on)))

@@ -399,6 +399,24 @@ print("graph ok")
     assert r.returncode == 0 and "graph ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_graph_replay_switched_on_per_handle(mods):
+    """ssvio_orb_set_graph: the same replay for one handle of a process; batches of two sizes, a size change, and back off again"""
+    S, synth, O = mods
+    g = S.ORBextractor(700, 1.2, 8, 20, 7); c = O.Extractor(700, 1.2, 8, 20, 7)
+    g.set_graph(True)
+    for (h, w) in ((240, 320), (300, 400), (240, 320)):
+        imgs = np.stack([synth.texture(60 + i, h, w) for i in range(4)])
+        for n in (4, 2, 4):
+            ks, ds, ns = g.extract_batch(imgs[:n])
+            for f in range(n):
+                rk, rd = c.extract(imgs[f])
+                assert ns[f] == len(rk) and np.array_equal(ks[f, :ns[f]].view(np.uint8), rk.view(np.uint8)) and np.array_equal(ds[f, :ns[f]], rd)
+    g.set_graph(False)
+    k, d = g.Extract(imgs[0]); rk, rd = c.extract(imgs[0])
+    assert np.array_equal(k.view(np.uint8), rk.view(np.uint8)) and np.array_equal(d, rd)
+    g.close()
+
+
 def test_copy_path_of_the_host_entry_points_gives_the_same_results():
     """Small host inputs are read from device-mapped memory by default; SSVIO_NO_MAPPED_INPUT=1 (read once per process, hence
     the child) sends the same calls down the copy path that large inputs take.  Both against the oracle, strided ROI included."""
