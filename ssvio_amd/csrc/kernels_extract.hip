@@ -517,20 +517,25 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* __restrict__ pyr, s
     const bool lane252 = tid < 252;
     constexpr uint32_t H = 0x80808080u, M7 = 0x7f7f7f7fu;
     {
+        // rows r0, r0 + 14, ...: one base per array and fixed offsets (14 rows = 252 dwords) instead of an index product per pass; the source
+        // offset is a 24-bit multiply-add (rows < 4128, pitch < 8192: a level is far below 4 GB) from the wave-uniform base
         uint32_t ld[kLoadPasses];
-        const int xoff = min(x0 - 4 + 4 * c0, xMaxLoad);
+        const uint32_t xoff = (uint32_t)min(x0 - 4 + 4 * c0, xMaxLoad);
+        constexpr int kPass = 14 * (kFtPitch / 4);
+        uint32_t* const tp = tile + r0 * (kFtPitch / 4) + c0;
+        uint32_t* const hp = half + r0 * (kFtPitch / 4) + c0;
+        uint32_t* const sp = sc + r0 * (kFtPitch / 4) + c0;
+        const int rLoad = lane252 ? ftRows - r0 : 0, rZero = lane252 ? scRows - r0 : 0;      // pass k loads / clears iff 14 k < rLoad / rZero
 #pragma unroll
         for (int k = 0; k < kLoadPasses; ++k) {
-            const int r = r0 + 14 * k;
-            const int yy = min(max(y0 - 4 + r, 0), h - 1);
-            // a level is far below 4 GB: 32-bit lane offsets from the wave-uniform base
-            ld[k] = (lane252 && r < ftRows) ? *(const uint32_t*)(img + ((uint32_t)yy * (uint32_t)pitch + (uint32_t)xoff)) : 0u;
+            int yy;
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(yy) : "v"(y0 - 4 + r0 + 14 * k), "v"(h - 1));
+            ld[k] = 14 * k < rLoad ? *(const uint32_t*)(img + (__umul24((uint32_t)yy, (uint32_t)pitch) + xoff)) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < kLoadPasses; ++k) {
-            const int r = r0 + 14 * k;
-            if (lane252 && r < ftRows) { tile[r * (kFtPitch / 4) + c0] = ld[k]; half[r * (kFtPitch / 4) + c0] = (ld[k] >> 1) & M7; }
-            if (lane252 && r < scRows) sc[r * (kFtPitch / 4) + c0] = 0;
+            if (14 * k < rLoad) { tp[kPass * k] = ld[k]; hp[kPass * k] = (ld[k] >> 1) & M7; }
+            if (14 * k < rZero) sp[kPass * k] = 0u;
         }
     }
     if (tid == 0) { qn = 0; cn = 0; on = 0; }
